@@ -1,0 +1,287 @@
+"""crystals-kyber_amd — Python host side of the MI355X batched ML-KEM engine.
+
+Thin ctypes binding over the C-ABI of libmlkem_amd.so (include/mlkem_batch.h).  PyTorch is used only as
+plumbing: device memory (uint8 / int16 CUDA tensors) and the current HIP stream.  The class mirrors the
+reference's operator surface for the hot path (rsjahnige/CRYSTALS-Kyber, ml_kem.c):
+
+    KeyGen_internal(d, z)   ml_kem.c:1034      Encaps_internal(ek, m)  ml_kem.c:1093
+    KEM_Decaps(dk, c)       ml_kem.c:1310      Decaps_internal(dk, c)  ml_kem.c:1136
+    NTT / InverseNTT / MultiplyNTTs / SampleNTT / SamplePolyCBD / PRF / H / G / J
+
+There is NO CPU fallback: importing works anywhere, but constructing `MLKEM` without a HIP device (or
+without the built extension) raises.  The directory name contains a hyphen, so import it through
+`__graft_entry__.load_package()` (importlib) — the module is registered as `crystals_kyber_amd`.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libmlkem_amd.so")
+SHIM_PATH = os.path.join(HERE, "libml_kem.so")
+
+SIZES = {512: (800, 1632, 768), 768: (1184, 2400, 1088), 1024: (1568, 3168, 1568)}  # ek, dk, c (ml_kem.h:52-59)
+ERR_HASH = -5
+
+# every symbol include/mlkem_batch.h declares (checked by tests/test_abi.py without a GPU)
+ABI_SYMBOLS = (
+    "mlkem_sizes", "mlkem_params", "mlkem_device_count", "mlkem_strerror", "mlkem_last_hip_error",
+    "mlkem_ctx_create", "mlkem_ctx_destroy", "mlkem_ctx_scratch_bytes",
+    "mlkem_keygen_dev", "mlkem_encaps_dev", "mlkem_decaps_dev",
+    "mlkem_ntt_dev", "mlkem_intt_dev", "mlkem_multiply_ntts_dev", "mlkem_sample_ntt_dev", "mlkem_sample_cbd_dev",
+    "mlkem_prf_dev", "mlkem_hash_dev",
+    "mlkem_keygen", "mlkem_encaps", "mlkem_decaps", "mlkem_ntt", "mlkem_intt",
+    "mlkem_keygen_random", "mlkem_encaps_random",
+)
+SHIM_SYMBOLS = ("init", "KEM_KeyGen", "KEM_Encaps", "KEM_Decaps", "ml_errno")
+
+
+class MLKEMError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"mlkem error {code}: {msg}")
+        self.code = code
+
+
+_lib = None
+
+
+def load_library():
+    """dlopen libmlkem_amd.so (fails loudly when the HIP extension has not been built)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FileNotFoundError(f"{LIB_PATH} missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                                "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp, sz, i32 = C.c_void_p, C.c_size_t, C.c_int
+    L.mlkem_strerror.restype = C.c_char_p
+    L.mlkem_last_hip_error.restype = C.c_char_p
+    L.mlkem_ctx_create.argtypes = [C.POINTER(vp), i32, sz]
+    L.mlkem_ctx_destroy.argtypes = [vp]
+    L.mlkem_ctx_destroy.restype = None
+    L.mlkem_ctx_scratch_bytes.argtypes = [vp]
+    L.mlkem_ctx_scratch_bytes.restype = sz
+    L.mlkem_keygen_dev.argtypes = [vp, i32, sz, vp, vp, vp, vp, vp]
+    L.mlkem_encaps_dev.argtypes = [vp, i32, sz, vp, vp, vp, vp, vp]
+    L.mlkem_decaps_dev.argtypes = [vp, i32, sz, vp, vp, vp, vp, vp]
+    L.mlkem_ntt_dev.argtypes = [vp, sz, vp, vp, vp]
+    L.mlkem_intt_dev.argtypes = [vp, sz, vp, vp, vp]
+    L.mlkem_multiply_ntts_dev.argtypes = [vp, sz, vp, vp, vp, vp]
+    L.mlkem_sample_ntt_dev.argtypes = [vp, sz, vp, vp, vp]
+    L.mlkem_sample_cbd_dev.argtypes = [vp, i32, sz, vp, vp, vp]
+    L.mlkem_prf_dev.argtypes = [vp, i32, sz, vp, vp, vp]
+    L.mlkem_hash_dev.argtypes = [vp, i32, sz, vp, C.c_uint, sz, vp, vp]
+    L.mlkem_keygen.argtypes = [i32, sz, vp, vp, vp, vp]
+    L.mlkem_encaps.argtypes = [i32, sz, vp, vp, vp, vp]
+    L.mlkem_decaps.argtypes = [i32, sz, vp, vp, vp, vp]
+    L.mlkem_ntt.argtypes = [sz, vp, vp]
+    L.mlkem_intt.argtypes = [sz, vp, vp]
+    L.mlkem_keygen_random.argtypes = [i32, sz, vp, vp]
+    L.mlkem_encaps_random.argtypes = [i32, sz, vp, C.c_uint, vp, vp]
+    _lib = L
+    return L
+
+
+def sizes(param_set):
+    if param_set not in SIZES:
+        raise MLKEMError(-1, "invalid parameter set (reference ml_errno -1, ml_kem.c:1389)")
+    return SIZES[param_set]
+
+
+class MLKEM:
+    """One engine context = one device + its scratch HBM.  Work is enqueued on torch's current stream."""
+
+    def __init__(self, param_set=768, device=0, chunk_items=0):
+        import torch
+        self.torch = torch
+        self.lib = load_library()
+        self.ek_len, self.dk_len, self.c_len = sizes(param_set)
+        self.param_set = param_set
+        if not torch.cuda.is_available():
+            raise MLKEMError(-100, "no HIP device visible (the engine has no CPU fallback)")
+        self.device = torch.device("cuda", device)
+        h = C.c_void_p()
+        self._check(self.lib.mlkem_ctx_create(C.byref(h), device, chunk_items))
+        self._ctx = h
+
+    def close(self):
+        if getattr(self, "_ctx", None):
+            self.lib.mlkem_ctx_destroy(self._ctx)
+            self._ctx = None
+
+    __del__ = close
+
+    # -- helpers -------------------------------------------------------------------------------
+    def _check(self, rc):
+        if rc != 0:
+            msg = self.lib.mlkem_strerror(rc).decode()
+            hip = self.lib.mlkem_last_hip_error().decode()
+            raise MLKEMError(rc, msg + (f" [{hip}]" if hip and rc == -100 else ""))
+
+    def _stream(self):
+        return C.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _dev(self, t, dtype, last):
+        torch = self.torch
+        if not isinstance(t, torch.Tensor):
+            t = torch.as_tensor(t)
+        t = t.to(device=self.device, dtype=dtype).contiguous()
+        if t.dim() == 1:
+            t = t.reshape(-1, last)
+        if t.dim() != 2 or t.shape[1] != last:
+            raise MLKEMError(-3, f"type check failed: expected rows of {last}, got {tuple(t.shape)} (reference ml_errno -3)")
+        return t
+
+    def _out(self, n, last, dtype=None):
+        torch = self.torch
+        return torch.empty((n, last), dtype=dtype or torch.uint8, device=self.device)
+
+    @property
+    def scratch_bytes(self):
+        return self.lib.mlkem_ctx_scratch_bytes(self._ctx)
+
+    # -- batched KEM (device resident) -------------------------------------------------------------
+    def keygen(self, d, z, ek=None, dk=None):
+        """KeyGen_internal (ml_kem.c:1034): d, z [n,32] -> ek [n,ek_len], dk [n,dk_len]."""
+        u8 = self.torch.uint8
+        d, z = self._dev(d, u8, 32), self._dev(z, u8, 32)
+        n = d.shape[0]
+        if z.shape[0] != n:
+            raise MLKEMError(-101, "d and z batch sizes differ")
+        ek = ek if ek is not None else self._out(n, self.ek_len)
+        dk = dk if dk is not None else self._out(n, self.dk_len)
+        self._check(self.lib.mlkem_keygen_dev(self._ctx, self.param_set, n, d.data_ptr(), z.data_ptr(), ek.data_ptr(),
+                                              dk.data_ptr(), self._stream()))
+        return ek, dk
+
+    def encaps(self, ek, m, c=None, K=None):
+        """Encaps_internal (ml_kem.c:1093): ek [n,ek_len], m [n,32] -> c [n,c_len], K [n,32]."""
+        u8 = self.torch.uint8
+        ek, m = self._dev(ek, u8, self.ek_len), self._dev(m, u8, 32)
+        n = m.shape[0]
+        if ek.shape[0] != n:
+            raise MLKEMError(-101, "ek and m batch sizes differ")
+        c = c if c is not None else self._out(n, self.c_len)
+        K = K if K is not None else self._out(n, 32)
+        self._check(self.lib.mlkem_encaps_dev(self._ctx, self.param_set, n, ek.data_ptr(), m.data_ptr(), c.data_ptr(),
+                                              K.data_ptr(), self._stream()))
+        return c, K
+
+    def decaps(self, dk, c, K=None, status=None, hash_check=True):
+        """KEM_Decaps (ml_kem.c:1310) incl. the dk hash check: -> K [n,32], status [n] (0 or -5).
+        hash_check=False gives Decaps_internal (ml_kem.c:1136) and status None."""
+        torch = self.torch
+        dk, c = self._dev(dk, torch.uint8, self.dk_len), self._dev(c, torch.uint8, self.c_len)
+        n = c.shape[0]
+        if dk.shape[0] != n:
+            raise MLKEMError(-101, "dk and c batch sizes differ")
+        K = K if K is not None else self._out(n, 32)
+        if hash_check and status is None:
+            status = torch.empty(n, dtype=torch.int32, device=self.device)
+        sp = status.data_ptr() if hash_check else None
+        self._check(self.lib.mlkem_decaps_dev(self._ctx, self.param_set, n, dk.data_ptr(), c.data_ptr(), K.data_ptr(), sp,
+                                              self._stream()))
+        return K, (status if hash_check else None)
+
+    # reference-style aliases
+    KeyGen_internal = keygen
+    Encaps_internal = encaps
+    KEM_Decaps = decaps
+
+    def Decaps_internal(self, dk, c):
+        return self.decaps(dk, c, hash_check=False)[0]
+
+    # -- batched primitives --------------------------------------------------------------------------
+    def _poly(self, f):
+        torch = self.torch
+        if not isinstance(f, torch.Tensor):
+            f = torch.as_tensor(f)
+        if f.dtype == torch.uint16:
+            f = f.view(torch.int16)
+        return self._dev(f, torch.int16, 256)
+
+    def ntt(self, f):
+        """NTT (ml_kem.c:287): [n,256] coefficients in [0,q) (int16 storage of uint16 values)."""
+        f = self._poly(f)
+        out = self.torch.empty_like(f)
+        self._check(self.lib.mlkem_ntt_dev(self._ctx, f.shape[0], f.data_ptr(), out.data_ptr(), self._stream()))
+        return out
+
+    def intt(self, fh):
+        """InverseNTT (ml_kem.c:336)."""
+        fh = self._poly(fh)
+        out = self.torch.empty_like(fh)
+        self._check(self.lib.mlkem_intt_dev(self._ctx, fh.shape[0], fh.data_ptr(), out.data_ptr(), self._stream()))
+        return out
+
+    def multiply_ntts(self, a, b):
+        """MultiplyNTTs (ml_kem.c:415)."""
+        a, b = self._poly(a), self._poly(b)
+        out = self.torch.empty_like(a)
+        self._check(self.lib.mlkem_multiply_ntts_dev(self._ctx, a.shape[0], a.data_ptr(), b.data_ptr(), out.data_ptr(),
+                                                     self._stream()))
+        return out
+
+    def sample_ntt(self, seeds34):
+        """SampleNTT (ml_kem.c:189): [n,34] -> [n,256]."""
+        s = self._dev(seeds34, self.torch.uint8, 34)
+        out = self._out(s.shape[0], 256, self.torch.int16)
+        self._check(self.lib.mlkem_sample_ntt_dev(self._ctx, s.shape[0], s.data_ptr(), out.data_ptr(), self._stream()))
+        return out
+
+    def sample_cbd(self, data, eta):
+        """SamplePolyCBD (ml_kem.c:253): [n,64*eta] -> [n,256]."""
+        b = self._dev(data, self.torch.uint8, 64 * eta)
+        out = self._out(b.shape[0], 256, self.torch.int16)
+        self._check(self.lib.mlkem_sample_cbd_dev(self._ctx, eta, b.shape[0], b.data_ptr(), out.data_ptr(), self._stream()))
+        return out
+
+    def prf(self, in33, eta):
+        """PRF (ml_kem.c:496; SHAKE128 in the reference): [n,33] (s || b) -> [n,64*eta]."""
+        s = self._dev(in33, self.torch.uint8, 33)
+        out = self._out(s.shape[0], 64 * eta)
+        self._check(self.lib.mlkem_prf_dev(self._ctx, eta, s.shape[0], s.data_ptr(), out.data_ptr(), self._stream()))
+        return out
+
+    def _hash(self, kind, msgs, outlen):
+        torch = self.torch
+        if not isinstance(msgs, torch.Tensor):
+            msgs = torch.as_tensor(msgs)
+        msgs = msgs.to(device=self.device, dtype=torch.uint8)
+        n, ln = msgs.shape
+        stride = (ln + 3) // 4 * 4 + 4
+        padded = torch.zeros((n, stride), dtype=torch.uint8, device=self.device)
+        padded[:, :ln] = msgs
+        out = self._out(n, outlen)
+        self._check(self.lib.mlkem_hash_dev(self._ctx, kind, n, padded.data_ptr(), ln, stride, out.data_ptr(), self._stream()))
+        return out
+
+    def H(self, msgs):
+        """H = SHA3-256 (ml_kem.c:521) over equal-length messages [n,len] -> [n,32]."""
+        return self._hash(0, msgs, 32)
+
+    def G(self, msgs):
+        """G = SHA3-512 (ml_kem.c:559) -> [n,64]."""
+        return self._hash(1, msgs, 64)
+
+    def J(self, msgs):
+        """J (ml_kem.c:540; SHAKE128 in the reference) -> [n,32]."""
+        return self._hash(2, msgs, 32)
+
+    # NTT-only workload of BASELINE config 2
+    NTT = ntt
+    InverseNTT = intt
+    MultiplyNTTs = multiply_ntts
+    SampleNTT = sample_ntt
+    SamplePolyCBD = sample_cbd
+    PRF = prf
+
+
+def shard_range(n_total, rank, world):
+    """Contiguous shard of a batch for rank `rank` of `world` (item i -> GPU floor(i / (B/G)));
+    the remainder is spread over the first ranks.  Returns (start, stop)."""
+    if world <= 0 or not (0 <= rank < world):
+        raise ValueError("bad rank/world")
+    base, rem = divmod(n_total, world)
+    start = rank * base + min(rank, rem)
+    return start, start + base + (1 if rank < rem else 0)

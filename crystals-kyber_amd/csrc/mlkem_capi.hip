@@ -1,0 +1,366 @@
+// mlkem_capi.hip — C-ABI of libmlkem_amd.so (include/mlkem_batch.h) over the gfx950 kernels.
+//
+// No CPU fallback exists here by design: every entry point either enqueues HIP kernels or fails with
+// MLKEM_ERR_NO_DEVICE / a HIP error.  The CPU oracle under oracle/ is test infrastructure and is never
+// linked or loaded by this library.
+#include "mlkem_pipeline.hpp"
+
+#include "../../include/mlkem_batch.h"
+
+#include <sys/random.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+using namespace mlkem;
+
+namespace {
+
+thread_local std::string g_last_hip_error;
+
+bool hip_ok(hipError_t e, const char* what) {
+    if (e == hipSuccess) return true;
+    g_last_hip_error = std::string(what) + ": " + hipGetErrorString(e);
+    return false;
+}
+#define HIP_TRY(expr)                                   \
+    do {                                                \
+        if (!hip_ok((expr), #expr)) return MLKEM_ERR_NO_DEVICE; \
+    } while (0)
+
+bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+size_t default_chunk() {
+    if (const char* e = getenv("MLKEM_CHUNK_ITEMS")) {
+        long long v = atoll(e);
+        if (v > 0) return (size_t)v;
+    }
+    return (size_t)1 << 17;
+}
+
+}   // namespace
+
+struct mlkem_ctx {
+    int device = 0;
+    size_t chunk = 0;
+    size_t scratch_bytes = 0;
+    void* scratch = nullptr;
+    Workspace ws;
+};
+
+extern "C" {
+
+int mlkem_sizes(int set, unsigned* ek_len, unsigned* dk_len, unsigned* c_len) {
+    ParamSet p;
+    if (!param_set(set, p)) return MLKEM_ERR_PARAM_SET;
+    if (ek_len) *ek_len = p.ek_len;
+    if (dk_len) *dk_len = p.dk_len;
+    if (c_len) *c_len = p.c_len;
+    return MLKEM_OK;
+}
+
+int mlkem_params(int set, int out[5]) {
+    ParamSet p;
+    if (!param_set(set, p)) return MLKEM_ERR_PARAM_SET;
+    if (!out) return MLKEM_ERR_ARG;
+    out[0] = p.k; out[1] = p.eta1; out[2] = p.eta2; out[3] = p.du; out[4] = p.dv;
+    return MLKEM_OK;
+}
+
+int mlkem_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char* mlkem_strerror(int code) {
+    switch (code) {
+    case MLKEM_OK: return "ok";
+    case MLKEM_ERR_PARAM_SET: return "invalid parameter set (reference ml_errno -1)";
+    case MLKEM_ERR_RNG: return "random bit generation failed (reference ml_errno -2)";
+    case MLKEM_ERR_LENGTH: return "type check failed: wrong ek/dk/c length (reference ml_errno -3)";
+    case MLKEM_ERR_MODULUS: return "modulus check failed (reference ml_errno -4; unreachable)";
+    case MLKEM_ERR_HASH: return "decapsulation key hash check failed (reference ml_errno -5)";
+    case MLKEM_ERR_NO_DEVICE: return "no usable HIP device / HIP runtime error (no CPU fallback exists)";
+    case MLKEM_ERR_ARG: return "bad argument (NULL or misaligned pointer)";
+    case MLKEM_ERR_ALLOC: return "allocation failed";
+    default: return "unknown error";
+    }
+}
+
+const char* mlkem_last_hip_error(void) { return g_last_hip_error.c_str(); }
+
+int mlkem_ctx_create(mlkem_ctx** out, int device, size_t chunk_items) {
+    if (!out) return MLKEM_ERR_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (!hip_ok(hipGetDeviceCount(&ndev), "hipGetDeviceCount") || ndev <= 0) return MLKEM_ERR_NO_DEVICE;
+    if (device < 0 || device >= ndev) return MLKEM_ERR_ARG;
+    HIP_TRY(hipSetDevice(device));
+    mlkem_ctx* c = new (std::nothrow) mlkem_ctx();
+    if (!c) return MLKEM_ERR_ALLOC;
+    c->device = device;
+    c->chunk = chunk_items ? chunk_items : default_chunk();
+    const size_t n = c->chunk;
+    // carve one allocation: A | prf | r | rho | m | Kp | Kbar, each 256-byte aligned
+    auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t szA = up(n * 16 * 512), szP = up(n * 9 * 192), sz32 = up(n * 32);
+    c->scratch_bytes = szA + szP + 5 * sz32;
+    if (!hip_ok(hipMalloc(&c->scratch, c->scratch_bytes), "hipMalloc(scratch)")) {
+        delete c;
+        return MLKEM_ERR_ALLOC;
+    }
+    uint8_t* base = static_cast<uint8_t*>(c->scratch);
+    c->ws.A = reinterpret_cast<uint16_t*>(base);
+    c->ws.prf = base + szA;
+    c->ws.r = c->ws.prf + szP;
+    c->ws.rho = c->ws.r + sz32;
+    c->ws.m = c->ws.rho + sz32;
+    c->ws.Kp = c->ws.m + sz32;
+    c->ws.Kbar = c->ws.Kp + sz32;
+    c->ws.cap_items = n;
+    *out = c;
+    return MLKEM_OK;
+}
+
+void mlkem_ctx_destroy(mlkem_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->scratch) (void)hipFree(ctx->scratch);
+    delete ctx;
+}
+
+size_t mlkem_ctx_scratch_bytes(const mlkem_ctx* ctx) { return ctx ? ctx->scratch_bytes : 0; }
+
+// ---- device-pointer KEM ------------------------------------------------------------------------------
+
+int mlkem_keygen_dev(mlkem_ctx* ctx, int set, size_t n, const uint8_t* d, const uint8_t* z, uint8_t* ek, uint8_t* dk, void* stream) {
+    ParamSet p;
+    if (!param_set(set, p)) return MLKEM_ERR_PARAM_SET;
+    if (!ctx || (n && (!d || !z || !ek || !dk))) return MLKEM_ERR_ARG;
+    if (!aligned16(d) || !aligned16(z) || !aligned16(ek) || !aligned16(dk)) return MLKEM_ERR_ARG;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    for (size_t off = 0; off < n; off += ctx->chunk) {
+        const size_t m = n - off < ctx->chunk ? n - off : ctx->chunk;
+        keygen_dispatch(st, set, m, d + off * 32, z + off * 32, ek + off * p.ek_len, dk + off * p.dk_len, ctx->ws);
+    }
+    HIP_TRY(hipGetLastError());
+    return MLKEM_OK;
+}
+
+int mlkem_encaps_dev(mlkem_ctx* ctx, int set, size_t n, const uint8_t* ek, const uint8_t* m, uint8_t* c, uint8_t* K, void* stream) {
+    ParamSet p;
+    if (!param_set(set, p)) return MLKEM_ERR_PARAM_SET;
+    if (!ctx || (n && (!ek || !m || !c || !K))) return MLKEM_ERR_ARG;
+    if (!aligned16(ek) || !aligned16(m) || !aligned16(c) || !aligned16(K)) return MLKEM_ERR_ARG;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    for (size_t off = 0; off < n; off += ctx->chunk) {
+        const size_t cnt = n - off < ctx->chunk ? n - off : ctx->chunk;
+        encaps_dispatch(st, set, cnt, ek + off * p.ek_len, m + off * 32, c + off * p.c_len, K + off * 32, ctx->ws);
+    }
+    HIP_TRY(hipGetLastError());
+    return MLKEM_OK;
+}
+
+int mlkem_decaps_dev(mlkem_ctx* ctx, int set, size_t n, const uint8_t* dk, const uint8_t* c, uint8_t* K, int32_t* status, void* stream) {
+    ParamSet p;
+    if (!param_set(set, p)) return MLKEM_ERR_PARAM_SET;
+    if (!ctx || (n && (!dk || !c || !K))) return MLKEM_ERR_ARG;
+    if (!aligned16(dk) || !aligned16(c) || !aligned16(K) || (reinterpret_cast<uintptr_t>(status) & 3u)) return MLKEM_ERR_ARG;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    for (size_t off = 0; off < n; off += ctx->chunk) {
+        const size_t cnt = n - off < ctx->chunk ? n - off : ctx->chunk;
+        decaps_dispatch(st, set, cnt, dk + off * p.dk_len, c + off * p.c_len, K + off * 32, status ? status + off : nullptr,
+                        status != nullptr, ctx->ws);
+    }
+    HIP_TRY(hipGetLastError());
+    return MLKEM_OK;
+}
+
+// ---- device-pointer primitives -------------------------------------------------------------------------
+
+int mlkem_ntt_dev(mlkem_ctx* ctx, size_t n, const uint16_t* f, uint16_t* fh, void* stream) {
+    if (!ctx || (n && (!f || !fh)) || !aligned16(f) || !aligned16(fh)) return MLKEM_ERR_ARG;
+    ntt_launch(static_cast<hipStream_t>(stream), false, n, f, fh);
+    HIP_TRY(hipGetLastError());
+    return MLKEM_OK;
+}
+int mlkem_intt_dev(mlkem_ctx* ctx, size_t n, const uint16_t* fh, uint16_t* f, void* stream) {
+    if (!ctx || (n && (!f || !fh)) || !aligned16(f) || !aligned16(fh)) return MLKEM_ERR_ARG;
+    ntt_launch(static_cast<hipStream_t>(stream), true, n, fh, f);
+    HIP_TRY(hipGetLastError());
+    return MLKEM_OK;
+}
+int mlkem_multiply_ntts_dev(mlkem_ctx* ctx, size_t n, const uint16_t* a, const uint16_t* b, uint16_t* h, void* stream) {
+    if (!ctx || (n && (!a || !b || !h)) || !aligned16(a) || !aligned16(b) || !aligned16(h)) return MLKEM_ERR_ARG;
+    basemul_launch(static_cast<hipStream_t>(stream), n, a, b, h);
+    HIP_TRY(hipGetLastError());
+    return MLKEM_OK;
+}
+int mlkem_sample_ntt_dev(mlkem_ctx* ctx, size_t n, const uint8_t* seeds34, uint16_t* a, void* stream) {
+    if (!ctx || (n && (!seeds34 || !a)) || !aligned16(a)) return MLKEM_ERR_ARG;
+    if (n) sample_ntt_launch(static_cast<hipStream_t>(stream), n, seeds34, a);
+    HIP_TRY(hipGetLastError());
+    return MLKEM_OK;
+}
+int mlkem_sample_cbd_dev(mlkem_ctx* ctx, int eta, size_t n, const uint8_t* bytes, uint16_t* f, void* stream) {
+    if (!ctx || (n && (!bytes || !f)) || !aligned16(bytes) || !aligned16(f)) return MLKEM_ERR_ARG;
+    if (cbd_launch(static_cast<hipStream_t>(stream), eta, n, bytes, f)) return MLKEM_ERR_ARG;
+    HIP_TRY(hipGetLastError());
+    return MLKEM_OK;
+}
+int mlkem_prf_dev(mlkem_ctx* ctx, int eta, size_t n, const uint8_t* in33, uint8_t* out, void* stream) {
+    if (!ctx || (n && (!in33 || !out)) || !aligned16(out)) return MLKEM_ERR_ARG;
+    if (n && prf_launch(static_cast<hipStream_t>(stream), eta, n, in33, out)) return MLKEM_ERR_ARG;
+    HIP_TRY(hipGetLastError());
+    return MLKEM_OK;
+}
+int mlkem_hash_dev(mlkem_ctx* ctx, int kind, size_t n, const uint8_t* msg, unsigned len, size_t stride, uint8_t* out, void* stream) {
+    if (!ctx || (n && (!msg || !out)) || !aligned16(msg) || !aligned16(out)) return MLKEM_ERR_ARG;
+    if (n && hash_launch(static_cast<hipStream_t>(stream), kind, n, msg, len, stride, out)) return MLKEM_ERR_ARG;
+    HIP_TRY(hipGetLastError());
+    return MLKEM_OK;
+}
+
+}   // extern "C"
+
+// ---- host-pointer variants -----------------------------------------------------------------------------
+namespace {
+
+std::mutex g_host_mu;
+mlkem_ctx* g_host_ctx = nullptr;
+
+int host_ctx(mlkem_ctx** out) {
+    if (!g_host_ctx) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+        int rc = mlkem_ctx_create(&g_host_ctx, dev, (size_t)1 << 16);
+        if (rc) return rc;
+    }
+    *out = g_host_ctx;
+    return MLKEM_OK;
+}
+
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    int alloc(size_t bytes) { return hip_ok(hipMalloc(&p, bytes ? bytes : 16), "hipMalloc") ? MLKEM_OK : MLKEM_ERR_ALLOC; }
+    template <class T> T* as() { return static_cast<T*>(p); }
+};
+
+}   // namespace
+
+extern "C" {
+
+int mlkem_keygen(int set, size_t n, const uint8_t* d, const uint8_t* z, uint8_t* ek, uint8_t* dk) {
+    ParamSet p;
+    if (!param_set(set, p)) return MLKEM_ERR_PARAM_SET;
+    if (n && (!d || !z || !ek || !dk)) return MLKEM_ERR_ARG;
+    std::lock_guard<std::mutex> lock(g_host_mu);
+    mlkem_ctx* ctx;
+    int rc = host_ctx(&ctx);
+    if (rc) return rc;
+    if (n == 0) return MLKEM_OK;
+    DevBuf bd, bz, bek, bdk;
+    if ((rc = bd.alloc(n * 32)) || (rc = bz.alloc(n * 32)) || (rc = bek.alloc(n * p.ek_len)) || (rc = bdk.alloc(n * p.dk_len))) return rc;
+    HIP_TRY(hipMemcpy(bd.p, d, n * 32, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(bz.p, z, n * 32, hipMemcpyHostToDevice));
+    rc = mlkem_keygen_dev(ctx, set, n, bd.as<uint8_t>(), bz.as<uint8_t>(), bek.as<uint8_t>(), bdk.as<uint8_t>(), nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(ek, bek.p, n * p.ek_len, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(dk, bdk.p, n * p.dk_len, hipMemcpyDeviceToHost));
+    return MLKEM_OK;
+}
+
+int mlkem_encaps(int set, size_t n, const uint8_t* ek, const uint8_t* m, uint8_t* c, uint8_t* K) {
+    ParamSet p;
+    if (!param_set(set, p)) return MLKEM_ERR_PARAM_SET;
+    if (n && (!ek || !m || !c || !K)) return MLKEM_ERR_ARG;
+    std::lock_guard<std::mutex> lock(g_host_mu);
+    mlkem_ctx* ctx;
+    int rc = host_ctx(&ctx);
+    if (rc) return rc;
+    if (n == 0) return MLKEM_OK;
+    DevBuf bek, bm, bc, bK;
+    if ((rc = bek.alloc(n * p.ek_len)) || (rc = bm.alloc(n * 32)) || (rc = bc.alloc(n * p.c_len)) || (rc = bK.alloc(n * 32))) return rc;
+    HIP_TRY(hipMemcpy(bek.p, ek, n * p.ek_len, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(bm.p, m, n * 32, hipMemcpyHostToDevice));
+    rc = mlkem_encaps_dev(ctx, set, n, bek.as<uint8_t>(), bm.as<uint8_t>(), bc.as<uint8_t>(), bK.as<uint8_t>(), nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(c, bc.p, n * p.c_len, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(K, bK.p, n * 32, hipMemcpyDeviceToHost));
+    return MLKEM_OK;
+}
+
+int mlkem_decaps(int set, size_t n, const uint8_t* dk, const uint8_t* c, uint8_t* K, int32_t* status) {
+    ParamSet p;
+    if (!param_set(set, p)) return MLKEM_ERR_PARAM_SET;
+    if (n && (!dk || !c || !K)) return MLKEM_ERR_ARG;
+    std::lock_guard<std::mutex> lock(g_host_mu);
+    mlkem_ctx* ctx;
+    int rc = host_ctx(&ctx);
+    if (rc) return rc;
+    if (n == 0) return MLKEM_OK;
+    DevBuf bdk, bc, bK, bs;
+    if ((rc = bdk.alloc(n * p.dk_len)) || (rc = bc.alloc(n * p.c_len)) || (rc = bK.alloc(n * 32)) || (rc = bs.alloc(n * 4))) return rc;
+    HIP_TRY(hipMemcpy(bdk.p, dk, n * p.dk_len, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(bc.p, c, n * p.c_len, hipMemcpyHostToDevice));
+    rc = mlkem_decaps_dev(ctx, set, n, bdk.as<uint8_t>(), bc.as<uint8_t>(), bK.as<uint8_t>(), status ? bs.as<int32_t>() : nullptr, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(K, bK.p, n * 32, hipMemcpyDeviceToHost));
+    if (status) HIP_TRY(hipMemcpy(status, bs.p, n * 4, hipMemcpyDeviceToHost));
+    return MLKEM_OK;
+}
+
+static int host_ntt(bool inverse, size_t n, const uint16_t* in, uint16_t* out) {
+    if (n && (!in || !out)) return MLKEM_ERR_ARG;
+    std::lock_guard<std::mutex> lock(g_host_mu);
+    mlkem_ctx* ctx;
+    int rc = host_ctx(&ctx);
+    if (rc) return rc;
+    if (n == 0) return MLKEM_OK;
+    DevBuf bi, bo;
+    if ((rc = bi.alloc(n * 512)) || (rc = bo.alloc(n * 512))) return rc;
+    HIP_TRY(hipMemcpy(bi.p, in, n * 512, hipMemcpyHostToDevice));
+    rc = inverse ? mlkem_intt_dev(ctx, n, bi.as<uint16_t>(), bo.as<uint16_t>(), nullptr)
+                 : mlkem_ntt_dev(ctx, n, bi.as<uint16_t>(), bo.as<uint16_t>(), nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(out, bo.p, n * 512, hipMemcpyDeviceToHost));
+    return MLKEM_OK;
+}
+int mlkem_ntt(size_t n, const uint16_t* f, uint16_t* fh) { return host_ntt(false, n, f, fh); }
+int mlkem_intt(size_t n, const uint16_t* fh, uint16_t* f) { return host_ntt(true, n, fh, f); }
+
+// ---- randomised wrappers: KEM_KeyGen / KEM_Encaps semantics at batch scale (ml_kem.c:458-478, :1233, :1257) --
+static bool fill_random(uint8_t* p, size_t n) {
+    while (n) {
+        ssize_t got = getrandom(p, n > 256 ? 256 : n, 0);
+        if (got <= 0) return false;
+        p += got;
+        n -= (size_t)got;
+    }
+    return true;
+}
+
+int mlkem_keygen_random(int set, size_t n, uint8_t* ek, uint8_t* dk) {
+    ParamSet p;
+    if (!param_set(set, p)) return MLKEM_ERR_PARAM_SET;
+    std::vector<uint8_t> d(n * 32 + 1), z(n * 32 + 1);
+    if (!fill_random(d.data(), n * 32) || !fill_random(z.data(), n * 32)) return MLKEM_ERR_RNG;
+    return mlkem_keygen(set, n, d.data(), z.data(), ek, dk);
+}
+
+int mlkem_encaps_random(int set, size_t n, const uint8_t* ek, unsigned ek_len, uint8_t* c, uint8_t* K) {
+    ParamSet p;
+    if (!param_set(set, p)) return MLKEM_ERR_PARAM_SET;
+    if (ek_len != p.ek_len) return MLKEM_ERR_LENGTH;   // ml_kem.c:1267-1271; the modulus check that follows is a no-op (F3)
+    std::vector<uint8_t> m(n * 32 + 1);
+    if (!fill_random(m.data(), n * 32)) return MLKEM_ERR_RNG;
+    return mlkem_encaps(set, n, ek, m.data(), c, K);
+}
+
+}   // extern "C"

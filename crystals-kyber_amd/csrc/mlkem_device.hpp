@@ -1,0 +1,421 @@
+// mlkem_device.hpp — gfx950 device building blocks for the batched ML-KEM engine.
+//
+// Everything here is wave64-native:
+//   * Keccak-f[1600] is lane-sliced (one sponge per lane, 25 lanes x 2 x u32 VGPRs) and built from
+//     v_bitop3_b32 (3-input LUT: xor3 for theta, a^(~b&c) for chi) and v_alignbit_b32 (64-bit rotates).
+//   * NTT / InverseNTT run one polynomial per wavefront, 4 coefficients per lane, radix-4 register
+//     stages with the three cross-lane re-layouts staged through wave-private LDS.
+//   * All modular arithmetic is exact integer work: signed Montgomery products (R = 2^16) with lazy
+//     reduction, Barrett reductions for canonicalisation; results are canonical in [0, q) and hence
+//     bit-identical to the reference's `% Q` arithmetic (ml_kem.c:287-442).
+//
+// Reference behaviour that is reproduced on purpose: PRF and J are SHAKE128
+// (ml_kem.c:508, :546), ByteDecode_12 does not reduce mod q (ml_kem.c:170).
+#pragma once
+#ifndef MLKEM_EMU
+#include <hip/hip_runtime.h>
+#endif
+#include <stdint.h>
+
+namespace mlkem {
+
+constexpr int KQ = 3329;
+constexpr int QINV16 = 62209;   // q^-1 mod 2^16
+constexpr int MONT = 2285;      // 2^16 mod q
+constexpr int MONT2 = 1353;     // 2^32 mod q
+constexpr int INV128 = 3303;    // 128^-1 mod q (ml_kem.c:378-381)
+
+// ----------------------------------------------------------------------------------------------
+// compile-time tables: zeta_i = 17^BitRev7(i) (ml_kem.c:300-307), stored in Montgomery form, centred
+// ----------------------------------------------------------------------------------------------
+constexpr int cx_bitrev7(int r) {
+    int o = 0;
+    for (int i = 0; i < 7; i++) o |= ((r >> i) & 1) << (6 - i);
+    return o;
+}
+constexpr int cx_pow17(int e) {
+    int r = 1;
+    for (int i = 0; i < e; i++) r = (r * 17) % KQ;
+    return r;
+}
+constexpr int cx_centered(int x) { return x > KQ / 2 ? x - KQ : x; }
+struct ZetaTable {
+    int16_t z[128];
+    constexpr ZetaTable() : z{} {
+        for (int i = 0; i < 128; i++) z[i] = (int16_t)cx_centered((cx_pow17(cx_bitrev7(i)) * MONT) % KQ);
+    }
+};
+__device__ const ZetaTable ZETA_MONT = ZetaTable();   // zeta_i * 2^16 mod q, centred
+
+// ----------------------------------------------------------------------------------------------
+// modular arithmetic
+// ----------------------------------------------------------------------------------------------
+// Montgomery reduction: t * 2^-16 mod q, result in (-q, q) for |t| < 2^31 - 2^15 q.
+__device__ __forceinline__ int mont_reduce(int t) {
+    int m = (int)(int16_t)(__umul24((unsigned)t, (unsigned)QINV16));   // low 16 bits, sign-extended
+    return (t - __mul24(m, KQ)) >> 16;
+}
+__device__ __forceinline__ int fqmul(int a, int b) { return mont_reduce(__mul24(a, b)); }
+
+// Barrett for |x| < 2^15: centred representative in [-(q-1)/2, (q-1)/2]
+__device__ __forceinline__ int barrett16(int x) {
+    int t = (x * 20159 + (1 << 25)) >> 26;
+    return x - t * KQ;
+}
+// cheap Barrett for |x| < 2^21: result in [-q, 2q)
+__device__ __forceinline__ int red21(int x) {
+    int t = (x * 315) >> 20;
+    return x - t * KQ;
+}
+// canonical representative in [0, q) of |x| < 2^15
+__device__ __forceinline__ int canon16(int x) {
+    int r = barrett16(x);
+    return r + ((r >> 31) & KQ);
+}
+
+// floor(num / q) for 0 <= num < 2^23 (exact: see DESIGN.md "division by q")
+__device__ __forceinline__ unsigned div_q(unsigned num) {
+    return (unsigned)(((uint64_t)num * 10321340ull) >> 35);
+}
+// Compress_d (ml_kem.c:83-97): round(2^d x / q) mod 2^d, ties cannot occur (q odd). x in [0, q).
+template <int D>
+__device__ __forceinline__ unsigned compress_d(unsigned x) {
+    static_assert(D >= 1 && D <= 11, "d");
+    return div_q((x << D) + (KQ / 2)) & ((1u << D) - 1);
+}
+// Decompress_d (ml_kem.c:104-119): floor(q y / 2^d) + (remainder >= 2^(d-1))
+template <int D>
+__device__ __forceinline__ unsigned decompress_d(unsigned y) {
+    static_assert(D >= 1 && D <= 11, "d");
+    return (KQ * y + (1u << (D - 1))) >> D;
+}
+
+// ----------------------------------------------------------------------------------------------
+// Keccak-f[1600], lane-sliced: state = 25 lanes x (lo, hi) u32.   sha3.c:15-216
+// ----------------------------------------------------------------------------------------------
+__constant__ uint32_t KECCAK_RC[48] = {   // (lo, hi) pairs of the 24 round constants (sha3.c:148-201)
+    0x00000001u, 0x00000000u, 0x00008082u, 0x00000000u, 0x0000808au, 0x80000000u, 0x80008000u, 0x80000000u,
+    0x0000808bu, 0x00000000u, 0x80000001u, 0x00000000u, 0x80008081u, 0x80000000u, 0x00008009u, 0x80000000u,
+    0x0000008au, 0x00000000u, 0x00000088u, 0x00000000u, 0x80008009u, 0x00000000u, 0x8000000au, 0x00000000u,
+    0x8000808bu, 0x00000000u, 0x0000008bu, 0x80000000u, 0x00008089u, 0x80000000u, 0x00008003u, 0x80000000u,
+    0x00008002u, 0x80000000u, 0x00000080u, 0x80000000u, 0x0000800au, 0x00000000u, 0x8000000au, 0x80000000u,
+    0x80008081u, 0x80000000u, 0x00008080u, 0x80000000u, 0x80000001u, 0x00000000u, 0x80008008u, 0x80000000u};
+
+#define MLKEM_XOR3(a, b, c) __builtin_amdgcn_bitop3_b32((a), (b), (c), 0x96)
+#define MLKEM_CHI(a, b, c) __builtin_amdgcn_bitop3_b32((a), (b), (c), 0xD2)   // a ^ (~b & c)
+
+struct KeccakState {
+    uint32_t lo[25], hi[25];
+};
+
+// 64-bit rotate-left by compile-time N of (lo, hi) via v_alignbit_b32
+template <int N>
+__device__ __forceinline__ void rotl64(uint32_t lo, uint32_t hi, uint32_t& olo, uint32_t& ohi) {
+    if constexpr (N == 0) {
+        olo = lo; ohi = hi;
+    } else if constexpr (N < 32) {
+        olo = __builtin_amdgcn_alignbit(lo, hi, 32 - N);
+        ohi = __builtin_amdgcn_alignbit(hi, lo, 32 - N);
+    } else if constexpr (N == 32) {
+        olo = hi; ohi = lo;
+    } else {
+        olo = __builtin_amdgcn_alignbit(hi, lo, 64 - N);
+        ohi = __builtin_amdgcn_alignbit(lo, hi, 64 - N);
+    }
+}
+
+#define MLKEM_RHOPI(dst, src, rot, dx)                                                       \
+    {                                                                                        \
+        uint32_t tl = MLKEM_XOR3(s.lo[src], cl[(dx + 4) % 5], rl[(dx + 1) % 5]);             \
+        uint32_t th = MLKEM_XOR3(s.hi[src], ch[(dx + 4) % 5], rh[(dx + 1) % 5]);             \
+        rotl64<rot>(tl, th, bl[dst], bh[dst]);                                               \
+    }
+
+__device__ __forceinline__ void keccak_f1600(KeccakState& s) {
+#pragma unroll 1
+    for (int round = 0; round < 24; round++) {
+        uint32_t cl[5], ch[5], rl[5], rh[5], bl[25], bh[25];
+        // theta (sha3.c:15-49): column parities, D[x] = C[x-1] ^ rotl(C[x+1], 1) folded into the xor3 below
+#pragma unroll
+        for (int x = 0; x < 5; x++) {
+            cl[x] = MLKEM_XOR3(MLKEM_XOR3(s.lo[x], s.lo[x + 5], s.lo[x + 10]), s.lo[x + 15], s.lo[x + 20]);
+            ch[x] = MLKEM_XOR3(MLKEM_XOR3(s.hi[x], s.hi[x + 5], s.hi[x + 10]), s.hi[x + 15], s.hi[x + 20]);
+        }
+#pragma unroll
+        for (int x = 0; x < 5; x++) rotl64<1>(cl[x], ch[x], rl[x], rh[x]);
+        // theta-apply + rho (sha3.c:53-84) + pi (sha3.c:88-112): B[y, 2x+3y] = rotl(A[x, y] ^ D[x], r[x, y])
+        MLKEM_RHOPI(0, 0, 0, 0)   MLKEM_RHOPI(10, 1, 1, 1)  MLKEM_RHOPI(20, 2, 62, 2) MLKEM_RHOPI(5, 3, 28, 3)  MLKEM_RHOPI(15, 4, 27, 4)
+        MLKEM_RHOPI(16, 5, 36, 0) MLKEM_RHOPI(1, 6, 44, 1)  MLKEM_RHOPI(11, 7, 6, 2)  MLKEM_RHOPI(21, 8, 55, 3) MLKEM_RHOPI(6, 9, 20, 4)
+        MLKEM_RHOPI(7, 10, 3, 0)  MLKEM_RHOPI(17, 11, 10, 1) MLKEM_RHOPI(2, 12, 43, 2) MLKEM_RHOPI(12, 13, 25, 3) MLKEM_RHOPI(22, 14, 39, 4)
+        MLKEM_RHOPI(23, 15, 41, 0) MLKEM_RHOPI(8, 16, 45, 1) MLKEM_RHOPI(18, 17, 15, 2) MLKEM_RHOPI(3, 18, 21, 3) MLKEM_RHOPI(13, 19, 8, 4)
+        MLKEM_RHOPI(14, 20, 18, 0) MLKEM_RHOPI(24, 21, 2, 1) MLKEM_RHOPI(9, 22, 61, 2) MLKEM_RHOPI(19, 23, 56, 3) MLKEM_RHOPI(4, 24, 14, 4)
+        // chi (sha3.c:116-140)
+#pragma unroll
+        for (int y = 0; y < 25; y += 5) {
+#pragma unroll
+            for (int x = 0; x < 5; x++) {
+                s.lo[y + x] = MLKEM_CHI(bl[y + x], bl[y + (x + 1) % 5], bl[y + (x + 2) % 5]);
+                s.hi[y + x] = MLKEM_CHI(bh[y + x], bh[y + (x + 1) % 5], bh[y + (x + 2) % 5]);
+            }
+        }
+        // iota (sha3.c:182-201)
+        s.lo[0] ^= KECCAK_RC[2 * round];
+        s.hi[0] ^= KECCAK_RC[2 * round + 1];
+    }
+}
+
+__device__ __forceinline__ void keccak_zero(KeccakState& s) {
+#pragma unroll
+    for (int i = 0; i < 25; i++) { s.lo[i] = 0; s.hi[i] = 0; }
+}
+
+// xor one byte into the state at compile-time byte position POS (pad / domain bytes)
+template <int POS>
+__device__ __forceinline__ void keccak_xor_byte(KeccakState& s, uint32_t byte) {
+    constexpr int w = POS / 4, sh = 8 * (POS % 4);
+    if constexpr (w % 2 == 0) s.lo[w / 2] ^= byte << sh;
+    else s.hi[w / 2] ^= byte << sh;
+}
+// state viewed as 50 dwords: dword w = (w even ? lo : hi)[w/2]
+template <int W>
+__device__ __forceinline__ uint32_t& keccak_word(KeccakState& s) {
+    if constexpr (W % 2 == 0) return s.lo[W / 2];
+    else return s.hi[W / 2];
+}
+
+// ----------------------------------------------------------------------------------------------
+// wave-level helpers
+// ----------------------------------------------------------------------------------------------
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+// Order wave-private LDS traffic between lanes of ONE wave (DS ops of a wave execute in issue order;
+// this only stops the compiler from moving them).
+__device__ __forceinline__ void wave_lds_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); }
+
+// ----------------------------------------------------------------------------------------------
+// One-polynomial-per-wave NTT.  Lane l holds 4 coefficients x[0..3]; layouts:
+//   NAT : c[4l + m]                      (contiguous; = basemul pair layout and HBM layout)
+//   LA  : c[l + 64 m]                    (layers len = 128, 64 in registers)
+//   LB  : c[64 (l/16) + (l%16) + 16 m]   (len = 32, 16)
+//   LC  : c[16 (l/4)  + (l%4)  +  4 m]   (len = 8, 4)
+//   NAT again for len = 2.
+// `xch` is a wave-private LDS buffer of 256 int16.
+// ----------------------------------------------------------------------------------------------
+struct NttTwiddles {   // per-lane Montgomery-form twiddles, loaded once per kernel
+    int fB0, fB1, fB2;   // forward stage B: zeta[4+blk], zeta[8+2blk], zeta[9+2blk]
+    int fC0, fC1, fC2;   // forward stage C: zeta[16+b16], zeta[32+2b16], zeta[33+2b16]
+    int fD;              // forward stage D: zeta[64+l]  (also gamma for basemul pair 2l; pair 2l+1 uses -fD)
+    int iD;              // inverse len=2 : zeta[127-l]
+    int iC0, iC1, iC2;   // inverse len=4 : zeta[63-2b16], zeta[62-2b16]; len=8: zeta[31-b16]
+    int iB0, iB1, iB2;   // inverse len=16: zeta[15-2blk], zeta[14-2blk]; len=32: zeta[7-blk]
+};
+__device__ __forceinline__ void load_twiddles(NttTwiddles& t) {
+    const int l = lane_id(), blk = l >> 4, b16 = l >> 2;
+    const int16_t* z = ZETA_MONT.z;
+    t.fB0 = z[4 + blk]; t.fB1 = z[8 + 2 * blk]; t.fB2 = z[9 + 2 * blk];
+    t.fC0 = z[16 + b16]; t.fC1 = z[32 + 2 * b16]; t.fC2 = z[33 + 2 * b16];
+    t.fD = z[64 + l];
+    t.iD = z[127 - l];
+    t.iC0 = z[63 - 2 * b16]; t.iC1 = z[62 - 2 * b16]; t.iC2 = z[31 - b16];
+    t.iB0 = z[15 - 2 * blk]; t.iB1 = z[14 - 2 * blk]; t.iB2 = z[7 - blk];
+}
+// wave-uniform twiddles (compile-time)
+constexpr int Z1 = cx_centered((cx_pow17(cx_bitrev7(1)) * MONT) % KQ);
+constexpr int Z2 = cx_centered((cx_pow17(cx_bitrev7(2)) * MONT) % KQ);
+constexpr int Z3 = cx_centered((cx_pow17(cx_bitrev7(3)) * MONT) % KQ);
+
+// Cooley-Tukey butterfly (ml_kem.c:311-324), lazy: outputs grow by < q per layer
+__device__ __forceinline__ void ct_bfly(int& a, int& b, int zeta) {
+    int t = fqmul(zeta, b);
+    b = a - t;
+    a = a + t;
+}
+// Gentleman-Sande butterfly (ml_kem.c:359-373), lazy
+__device__ __forceinline__ void gs_bfly(int& a, int& b, int zeta) {
+    int t = a;
+    a = t + b;
+    b = fqmul(zeta, b - t);
+}
+
+__device__ __forceinline__ int idx_LA(int l, int m) { return l + 64 * m; }
+__device__ __forceinline__ int idx_LB(int l, int m) { return 64 * (l >> 4) + (l & 15) + 16 * m; }
+__device__ __forceinline__ int idx_LC(int l, int m) { return 16 * (l >> 2) + (l & 3) + 4 * m; }
+
+// write 4 strided coefficients / read 4 strided coefficients through the exchange buffer
+#define MLKEM_XCH_WRITE(IDX)                                          \
+    {                                                                 \
+        _Pragma("unroll") for (int m = 0; m < 4; m++) xch[IDX(l, m)] = (int16_t)x[m]; \
+    }
+#define MLKEM_XCH_READ(IDX)                                           \
+    {                                                                 \
+        _Pragma("unroll") for (int m = 0; m < 4; m++) x[m] = xch[IDX(l, m)]; \
+    }
+__device__ __forceinline__ void xch_write_nat(int16_t* xch, int l, const int (&x)[4]) {
+    uint2 v;
+    v.x = ((uint32_t)x[0] & 0xFFFFu) | ((uint32_t)x[1] << 16);
+    v.y = ((uint32_t)x[2] & 0xFFFFu) | ((uint32_t)x[3] << 16);
+    *reinterpret_cast<uint2*>(xch + 4 * l) = v;
+}
+__device__ __forceinline__ void xch_read_nat(const int16_t* xch, int l, int (&x)[4]) {
+    uint2 v = *reinterpret_cast<const uint2*>(xch + 4 * l);
+    x[0] = (int)(int16_t)(v.x & 0xFFFFu); x[1] = (int)v.x >> 16;
+    x[2] = (int)(int16_t)(v.y & 0xFFFFu); x[3] = (int)v.y >> 16;
+}
+
+// Forward NTT (ml_kem.c:287-329).  In: NAT layout, |x| < q.  Out: NAT layout, |x| < 8q (lazy).
+__device__ __forceinline__ void wave_ntt(int (&x)[4], int16_t* xch, const NttTwiddles& tw) {
+    const int l = lane_id();
+    xch_write_nat(xch, l, x);
+    wave_lds_fence();
+    MLKEM_XCH_READ(idx_LA)
+    ct_bfly(x[0], x[2], Z1); ct_bfly(x[1], x[3], Z1);          // len = 128
+    ct_bfly(x[0], x[1], Z2); ct_bfly(x[2], x[3], Z3);          // len = 64
+    wave_lds_fence();
+    MLKEM_XCH_WRITE(idx_LA)
+    wave_lds_fence();
+    MLKEM_XCH_READ(idx_LB)
+    ct_bfly(x[0], x[2], tw.fB0); ct_bfly(x[1], x[3], tw.fB0);  // len = 32
+    ct_bfly(x[0], x[1], tw.fB1); ct_bfly(x[2], x[3], tw.fB2);  // len = 16
+    wave_lds_fence();
+    MLKEM_XCH_WRITE(idx_LB)
+    wave_lds_fence();
+    MLKEM_XCH_READ(idx_LC)
+    ct_bfly(x[0], x[2], tw.fC0); ct_bfly(x[1], x[3], tw.fC0);  // len = 8
+    ct_bfly(x[0], x[1], tw.fC1); ct_bfly(x[2], x[3], tw.fC2);  // len = 4
+    wave_lds_fence();
+    MLKEM_XCH_WRITE(idx_LC)
+    wave_lds_fence();
+    xch_read_nat(xch, l, x);
+    ct_bfly(x[0], x[2], tw.fD); ct_bfly(x[1], x[3], tw.fD);    // len = 2
+    wave_lds_fence();
+}
+
+// Inverse NTT (ml_kem.c:336-384).  In: NAT layout, |x| < 2^21.  Out: NAT layout, in (-q, q), multiplied by
+// `final_mont` through a Montgomery product (3303*R for plain inputs, 3303*R^2 for inputs carrying R^-1).
+__device__ __forceinline__ void wave_intt(int (&x)[4], int16_t* xch, const NttTwiddles& tw, int final_mont) {
+    const int l = lane_id();
+#pragma unroll
+    for (int m = 0; m < 4; m++) x[m] = red21(x[m]);              // < 2q
+    gs_bfly(x[0], x[2], tw.iD); gs_bfly(x[1], x[3], tw.iD);      // len = 2   -> < 4q
+    xch_write_nat(xch, l, x);
+    wave_lds_fence();
+    MLKEM_XCH_READ(idx_LC)
+#pragma unroll
+    for (int m = 0; m < 4; m++) x[m] = red21(x[m]);
+    gs_bfly(x[0], x[1], tw.iC0); gs_bfly(x[2], x[3], tw.iC1);    // len = 4
+    gs_bfly(x[0], x[2], tw.iC2); gs_bfly(x[1], x[3], tw.iC2);    // len = 8   -> < 8q
+    wave_lds_fence();
+    MLKEM_XCH_WRITE(idx_LC)
+    wave_lds_fence();
+    MLKEM_XCH_READ(idx_LB)
+#pragma unroll
+    for (int m = 0; m < 4; m++) x[m] = red21(x[m]);
+    gs_bfly(x[0], x[1], tw.iB0); gs_bfly(x[2], x[3], tw.iB1);    // len = 16
+    gs_bfly(x[0], x[2], tw.iB2); gs_bfly(x[1], x[3], tw.iB2);    // len = 32
+    wave_lds_fence();
+    MLKEM_XCH_WRITE(idx_LB)
+    wave_lds_fence();
+    MLKEM_XCH_READ(idx_LA)
+#pragma unroll
+    for (int m = 0; m < 4; m++) x[m] = red21(x[m]);
+    gs_bfly(x[0], x[1], Z3); gs_bfly(x[2], x[3], Z2);            // len = 64
+    gs_bfly(x[0], x[2], Z1); gs_bfly(x[1], x[3], Z1);            // len = 128
+#pragma unroll
+    for (int m = 0; m < 4; m++) x[m] = fqmul(x[m], final_mont);  // x 128^-1 (ml_kem.c:378-381)
+    wave_lds_fence();
+    MLKEM_XCH_WRITE(idx_LA)
+    wave_lds_fence();
+    xch_read_nat(xch, l, x);
+    wave_lds_fence();
+}
+constexpr int INTT_FINAL_PLAIN = cx_centered((INV128 * MONT) % KQ);                 // 3303 * R
+constexpr int INTT_FINAL_DEMONT = cx_centered((((INV128 * MONT) % KQ) * MONT) % KQ); // 3303 * R^2
+
+// ----------------------------------------------------------------------------------------------
+// bit-packed codecs (ml_kem.c:125-177) through a wave-private LDS byte buffer.
+// Lane l owns coefficients 4l..4l+3, i.e. bits [4 l d, 4 l d + 4 d) of the stream.
+// `buf` must hold 32*d bytes rounded up to a dword multiple plus 8 bytes of slack.
+// ----------------------------------------------------------------------------------------------
+constexpr int CODEC_BUF_WORDS = 96 + 4;   // 384 B (d = 12) + slack
+
+// stage 32*D bytes from global (dword-aligned) into LDS
+template <int D>
+__device__ __forceinline__ void codec_load_bytes(uint32_t* buf, const uint8_t* g) {
+    const int l = lane_id();
+    const uint32_t* gw = reinterpret_cast<const uint32_t*>(g);
+#pragma unroll
+    for (int w = l; w < 8 * D; w += 64) buf[w] = gw[w];
+    if (l < 4) buf[8 * D + l] = 0;
+}
+// ByteDecode_D: 4 values per lane (raw D-bit fields; no reduction even for D = 12: ml_kem.c:170, F3)
+template <int D>
+__device__ __forceinline__ void codec_decode(const uint32_t* buf, unsigned (&v)[4]) {
+    const int l = lane_id();
+    const unsigned bit = 4u * D * (unsigned)l, w = bit >> 5, sh = bit & 31;
+    uint32_t d0 = buf[w], d1 = buf[w + 1], d2 = buf[w + 2];
+    uint64_t lo = ((uint64_t)d1 << 32) | d0;
+    uint64_t val = sh ? ((lo >> sh) | ((uint64_t)d2 << (64 - sh))) : lo;
+#pragma unroll
+    for (int m = 0; m < 4; m++) v[m] = (unsigned)(val >> (m * D)) & ((1u << D) - 1);
+}
+// ByteEncode_D: each lane ORs its 4*D bits into a zeroed buffer
+template <int D>
+__device__ __forceinline__ void codec_zero(uint32_t* buf) {
+    const int l = lane_id();
+#pragma unroll
+    for (int w = l; w < 8 * D + 4; w += 64) buf[w] = 0;
+}
+template <int D>
+__device__ __forceinline__ void codec_encode(uint32_t* buf, const unsigned (&v)[4]) {
+    const int l = lane_id();
+    uint64_t val = 0;
+#pragma unroll
+    for (int m = 0; m < 4; m++) val |= (uint64_t)(v[m] & ((1u << D) - 1)) << (m * D);
+    const unsigned bit = 4u * D * (unsigned)l, w = bit >> 5, sh = bit & 31;
+    uint64_t lo = val << sh;
+    uint32_t hi = sh ? (uint32_t)(val >> (64 - sh)) : 0u;
+    atomicOr(&buf[w], (uint32_t)lo);
+    atomicOr(&buf[w + 1], (uint32_t)(lo >> 32));
+    if (4 * D + 31 > 64) atomicOr(&buf[w + 2], hi);
+}
+// write 32*D bytes LDS -> global (dword-aligned)
+template <int D>
+__device__ __forceinline__ void codec_store_bytes(const uint32_t* buf, uint8_t* g) {
+    const int l = lane_id();
+    uint32_t* gw = reinterpret_cast<uint32_t*>(g);
+#pragma unroll
+    for (int w = l; w < 8 * D; w += 64) gw[w] = buf[w];
+}
+// compare 32*D bytes LDS vs global; returns nonzero in some lane iff any dword differs
+template <int D>
+__device__ __forceinline__ uint32_t codec_diff_bytes(const uint32_t* buf, const uint8_t* g) {
+    const int l = lane_id();
+    const uint32_t* gw = reinterpret_cast<const uint32_t*>(g);
+    uint32_t diff = 0;
+#pragma unroll
+    for (int w = l; w < 8 * D; w += 64) diff |= buf[w] ^ gw[w];
+    return diff;
+}
+
+// ----------------------------------------------------------------------------------------------
+// SamplePolyCBD (ml_kem.c:253-275) for the lane's 4 coefficients (NAT layout), centred output in [-eta, eta]
+// `prf` points at the 64*eta PRF bytes of this polynomial in global memory.
+// ----------------------------------------------------------------------------------------------
+template <int ETA>
+__device__ __forceinline__ void cbd_nat(const uint8_t* prf, int (&x)[4]) {
+    const int l = lane_id();
+    if constexpr (ETA == 2) {
+        // 4 coefficients = 16 bits = bytes 2l, 2l+1
+        unsigned t = *reinterpret_cast<const uint16_t*>(prf + 2 * l);
+        unsigned d = (t & 0x5555u) + ((t >> 1) & 0x5555u);   // pairwise bit sums
+#pragma unroll
+        for (int m = 0; m < 4; m++) x[m] = (int)((d >> (4 * m)) & 3u) - (int)((d >> (4 * m + 2)) & 3u);
+    } else {
+        // 4 coefficients = 24 bits = bytes 3l..3l+2
+        unsigned t = (unsigned)prf[3 * l] | ((unsigned)prf[3 * l + 1] << 8) | ((unsigned)prf[3 * l + 2] << 16);
+        unsigned d = (t & 0x249249u) + ((t >> 1) & 0x249249u) + ((t >> 2) & 0x249249u);   // 3-bit group sums
+#pragma unroll
+        for (int m = 0; m < 4; m++) x[m] = (int)((d >> (6 * m)) & 7u) - (int)((d >> (6 * m + 3)) & 7u);
+    }
+}
+
+}   // namespace mlkem

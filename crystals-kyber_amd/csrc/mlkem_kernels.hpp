@@ -1,0 +1,828 @@
+// mlkem_kernels.hpp — the gfx950 kernels of the batched ML-KEM engine (kernel bodies only; launch code and
+// the C-ABI live in mlkem_capi.hip).
+//
+// Kernel families:
+//   k_hash_*      lane = one KEM instance; serial sponges H / G / J with inputs staged through LDS so that
+//                 the packed per-item byte strings are read from HBM in coalesced runs
+//   k_sample      lane = one SHAKE128 sponge; role XOF -> SampleNTT rejection sampling (ml_kem.c:189) with
+//                 an LDS ring per lane flushed in aligned 128-byte chunks; role PRF -> raw PRF bytes (ml_kem.c:496)
+//   k_keygen / k_encrypt / k_decrypt
+//                 wave = one KEM instance: CBD, NTT, base-case multiply-accumulate, inverse NTT, compress,
+//                 ByteEncode/Decode, ciphertext compare + key select, all in registers/LDS
+//   k_*_batch     stand-alone primitives behind the C-ABI (NTT-only workload of BASELINE config 2, parity tests)
+//
+// No kernel uses a workgroup barrier: every wave is independent, LDS is carved per wave.
+#pragma once
+#include "mlkem_device.hpp"
+
+namespace mlkem {
+
+constexpr int WAVE = 64;
+
+// ================================================================================================
+// LDS-staged absorption: 64 lanes each own one sponge; the wave cooperatively reads, for every item,
+// the next `nbytes` of a virtual message made of two segments (seg0 then seg1), each with its own
+// base / per-item stride, and every lane then XORs its row into its state.
+// Row stride in the stage is RATE/4 + 1 dwords (odd) so the per-lane row reads are bank-conflict free.
+// ================================================================================================
+struct MsgView {
+    const uint8_t* p0; size_t stride0; unsigned len0;   // segment 0 (may have len0 = 0)
+    const uint8_t* p1; size_t stride1; unsigned len1;   // segment 1
+};
+
+__device__ __forceinline__ uint32_t load_word_tail(const uint8_t* p, unsigned avail) {
+    // p is 4-byte aligned; `avail` (1..) bytes are readable
+    if (avail >= 4) return *reinterpret_cast<const uint32_t*>(p);
+    uint32_t v = p[0];
+    if (avail > 1) v |= (uint32_t)p[1] << 8;
+    if (avail > 2) v |= (uint32_t)p[2] << 16;
+    return v;
+}
+
+template <int RATE>
+__device__ __forceinline__ void wave_stage_block(uint32_t* stage, const MsgView& mv, size_t item0, size_t n_items,
+                                                 unsigned voff, unsigned nbytes) {
+    constexpr int RS = RATE / 4 + 1;
+    const int l = lane_id();
+    const unsigned nwords = (nbytes + 3) / 4;
+    const unsigned pos = voff + 4u * (unsigned)l;   // virtual byte offset of this lane's dword
+    if ((unsigned)l < nwords) {
+        for (int row = 0; row < WAVE; row++) {
+            size_t item = item0 + (size_t)row;
+            if (item >= n_items) item = n_items - 1;   // clamp: rows beyond the batch are computed but never stored
+            uint32_t v;
+            if (pos < mv.len0) v = load_word_tail(mv.p0 + item * mv.stride0 + pos, mv.len0 - pos);
+            else v = load_word_tail(mv.p1 + item * mv.stride1 + (pos - mv.len0), mv.len0 + mv.len1 - pos);
+            stage[row * RS + l] = v;
+        }
+    }
+}
+
+// XOR the first `nwords` dwords of this lane's staged row into its state
+template <int RATE>
+__device__ __forceinline__ void lane_xor_row(KeccakState& s, const uint32_t* stage, unsigned nwords) {
+    constexpr int RS = RATE / 4 + 1;
+    const uint32_t* row = stage + lane_id() * RS;
+#define MLKEM_XW(W) if constexpr (W < RATE / 4) { if ((unsigned)W < nwords) keccak_word<W>(s) ^= row[W]; }
+    MLKEM_XW(0) MLKEM_XW(1) MLKEM_XW(2) MLKEM_XW(3) MLKEM_XW(4) MLKEM_XW(5) MLKEM_XW(6) MLKEM_XW(7)
+    MLKEM_XW(8) MLKEM_XW(9) MLKEM_XW(10) MLKEM_XW(11) MLKEM_XW(12) MLKEM_XW(13) MLKEM_XW(14) MLKEM_XW(15)
+    MLKEM_XW(16) MLKEM_XW(17) MLKEM_XW(18) MLKEM_XW(19) MLKEM_XW(20) MLKEM_XW(21) MLKEM_XW(22) MLKEM_XW(23)
+    MLKEM_XW(24) MLKEM_XW(25) MLKEM_XW(26) MLKEM_XW(27) MLKEM_XW(28) MLKEM_XW(29) MLKEM_XW(30) MLKEM_XW(31)
+    MLKEM_XW(32) MLKEM_XW(33) MLKEM_XW(34) MLKEM_XW(35) MLKEM_XW(36) MLKEM_XW(37) MLKEM_XW(38) MLKEM_XW(39)
+    MLKEM_XW(40) MLKEM_XW(41)
+#undef MLKEM_XW
+}
+
+// xor `byte` at runtime byte position `pos` (wave-uniform) — used for the domain/pad byte of a
+// message whose length is only known at run time
+__device__ __forceinline__ void keccak_xor_byte_rt(KeccakState& s, unsigned pos, uint32_t byte) {
+    const unsigned w = pos >> 2;
+    const uint32_t v = byte << (8 * (pos & 3));
+#define MLKEM_XB(W) if (w == W) keccak_word<W>(s) ^= v;
+    MLKEM_XB(0) MLKEM_XB(1) MLKEM_XB(2) MLKEM_XB(3) MLKEM_XB(4) MLKEM_XB(5) MLKEM_XB(6) MLKEM_XB(7)
+    MLKEM_XB(8) MLKEM_XB(9) MLKEM_XB(10) MLKEM_XB(11) MLKEM_XB(12) MLKEM_XB(13) MLKEM_XB(14) MLKEM_XB(15)
+    MLKEM_XB(16) MLKEM_XB(17) MLKEM_XB(18) MLKEM_XB(19) MLKEM_XB(20) MLKEM_XB(21) MLKEM_XB(22) MLKEM_XB(23)
+    MLKEM_XB(24) MLKEM_XB(25) MLKEM_XB(26) MLKEM_XB(27) MLKEM_XB(28) MLKEM_XB(29) MLKEM_XB(30) MLKEM_XB(31)
+    MLKEM_XB(32) MLKEM_XB(33) MLKEM_XB(34) MLKEM_XB(35) MLKEM_XB(36) MLKEM_XB(37) MLKEM_XB(38) MLKEM_XB(39)
+    MLKEM_XB(40) MLKEM_XB(41)
+#undef MLKEM_XB
+}
+
+// Full sponge absorb of a (two-segment) message of wave-uniform length; leaves the state after the
+// final permutation (ready to squeeze).  sha3.c:257-291 + :408-436; SUFFIX = 0x06 (SHA-3) / 0x1F (SHAKE).
+template <int RATE, int SUFFIX>
+__device__ __forceinline__ void wave_sponge_absorb(KeccakState& s, uint32_t* stage, const MsgView& mv, size_t item0,
+                                                   size_t n_items) {
+    const unsigned total = mv.len0 + mv.len1;
+    keccak_zero(s);
+    unsigned voff = 0;
+    while (total - voff >= (unsigned)RATE) {
+        wave_stage_block<RATE>(stage, mv, item0, n_items, voff, RATE);
+        wave_lds_fence();
+        lane_xor_row<RATE>(s, stage, RATE / 4);
+        wave_lds_fence();
+        keccak_f1600(s);
+        voff += RATE;
+    }
+    const unsigned rem = total - voff;
+    if (rem) {
+        wave_stage_block<RATE>(stage, mv, item0, n_items, voff, rem);
+        wave_lds_fence();
+        lane_xor_row<RATE>(s, stage, (rem + 3) / 4);
+        wave_lds_fence();
+    }
+    keccak_xor_byte_rt(s, rem, SUFFIX);
+    keccak_xor_byte<RATE - 1>(s, 0x80);
+    keccak_f1600(s);
+}
+
+constexpr int STAGE_WORDS = WAVE * (168 / 4 + 1);   // largest rate (SHAKE128)
+
+// store / load 8 dwords (32 bytes) of per-item data: row `item` of a [n][32]-byte array
+__device__ __forceinline__ void store32(uint8_t* base, size_t stride, size_t item, const uint32_t (&w)[8]) {
+    uint32_t* p = reinterpret_cast<uint32_t*>(base + item * stride);
+#pragma unroll
+    for (int i = 0; i < 8; i++) p[i] = w[i];
+}
+__device__ __forceinline__ void load32(const uint8_t* base, size_t stride, size_t item, uint32_t (&w)[8]) {
+    const uint32_t* p = reinterpret_cast<const uint32_t*>(base + item * stride);
+#pragma unroll
+    for (int i = 0; i < 8; i++) w[i] = p[i];
+}
+#define MLKEM_STATE_WORDS8(s, FIRST, w)                                                             \
+    {                                                                                               \
+        w[0] = keccak_word<FIRST + 0>(s); w[1] = keccak_word<FIRST + 1>(s); w[2] = keccak_word<FIRST + 2>(s); \
+        w[3] = keccak_word<FIRST + 3>(s); w[4] = keccak_word<FIRST + 4>(s); w[5] = keccak_word<FIRST + 5>(s); \
+        w[6] = keccak_word<FIRST + 6>(s); w[7] = keccak_word<FIRST + 7>(s);                         \
+    }
+#define MLKEM_SET_WORDS8(s, FIRST, w)                                                               \
+    {                                                                                               \
+        keccak_word<FIRST + 0>(s) = w[0]; keccak_word<FIRST + 1>(s) = w[1]; keccak_word<FIRST + 2>(s) = w[2]; \
+        keccak_word<FIRST + 3>(s) = w[3]; keccak_word<FIRST + 4>(s) = w[4]; keccak_word<FIRST + 5>(s) = w[5]; \
+        keccak_word<FIRST + 6>(s) = w[6]; keccak_word<FIRST + 7>(s) = w[7];                         \
+    }
+
+// G(x || y) for two 32-byte halves already in registers: SHA3-512, one permutation (ml_kem.c:559-572)
+__device__ __forceinline__ void lane_G64(KeccakState& s, const uint32_t (&x)[8], const uint32_t (&y)[8]) {
+    keccak_zero(s);
+    MLKEM_SET_WORDS8(s, 0, x)
+    MLKEM_SET_WORDS8(s, 8, y)
+    keccak_xor_byte<64>(s, 0x06);
+    keccak_xor_byte<71>(s, 0x80);
+    keccak_f1600(s);
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_hash_encaps — Encaps_internal's hashing (ml_kem.c:1108-1124): h = H(ek); (K, r) = G(m || h)
+// ------------------------------------------------------------------------------------------------
+template <int K>
+__global__ void __launch_bounds__(WAVE) k_hash_encaps(size_t n, const uint8_t* __restrict__ ek, const uint8_t* __restrict__ m,
+                                                      uint8_t* __restrict__ Kout, uint8_t* __restrict__ r_ws) {
+    __shared__ uint32_t stage[STAGE_WORDS];
+    constexpr unsigned EK = 384 * K + 32;
+    const size_t item0 = (size_t)blockIdx.x * WAVE, item = item0 + lane_id();
+    KeccakState s;
+    MsgView mv{ek, EK, EK, ek, EK, 0};
+    wave_sponge_absorb<136, 0x06>(s, stage, mv, item0, n);
+    uint32_t h[8], mm[8], w[8];
+    MLKEM_STATE_WORDS8(s, 0, h)
+    const size_t it = item < n ? item : n - 1;
+    load32(m, 32, it, mm);
+    lane_G64(s, mm, h);
+    if (item < n) {
+        MLKEM_STATE_WORDS8(s, 0, w)
+        store32(Kout, 32, item, w);
+        MLKEM_STATE_WORDS8(s, 8, w)
+        store32(r_ws, 32, item, w);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_hash_decaps — KEM_Decaps hash check (ml_kem.c:1336-1350) and Decaps_internal's hashing
+// (ml_kem.c:1187-1202): status = (H(dk.ek) == dk.h) ? 0 : -5 ; (K', r') = G(m' || dk.h) ; Kbar = J(dk.z || c)
+// J is SHAKE128 in the reference (F2).
+// ------------------------------------------------------------------------------------------------
+template <int K, int CLEN, bool HASH_CHECK>
+__global__ void __launch_bounds__(WAVE) k_hash_decaps(size_t n, const uint8_t* __restrict__ dk, const uint8_t* __restrict__ c,
+                                                      const uint8_t* __restrict__ m_ws, uint8_t* __restrict__ Kp_ws,
+                                                      uint8_t* __restrict__ r_ws, uint8_t* __restrict__ Kbar_ws,
+                                                      int32_t* __restrict__ status) {
+    __shared__ uint32_t stage[STAGE_WORDS];
+    constexpr unsigned EK = 384 * K + 32, DK = 768 * K + 96;
+    const size_t item0 = (size_t)blockIdx.x * WAVE, item = item0 + lane_id();
+    const size_t it = item < n ? item : n - 1;
+    KeccakState s;
+    uint32_t h[8], w[8];
+    load32(dk + 768 * K + 32, DK, it, h);
+    int st = 0;
+    if constexpr (HASH_CHECK) {
+        MsgView mv{dk + 384 * K, DK, EK, dk, DK, 0};
+        wave_sponge_absorb<136, 0x06>(s, stage, mv, item0, n);
+        MLKEM_STATE_WORDS8(s, 0, w)
+        uint32_t diff = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) diff |= w[i] ^ h[i];
+        st = diff ? -5 : 0;
+    }
+    // Kbar = J(z || c)
+    {
+        MsgView mv{dk + 768 * K + 64, DK, 32, c, CLEN, CLEN};
+        wave_sponge_absorb<168, 0x1F>(s, stage, mv, item0, n);
+        if (item < n) {
+            MLKEM_STATE_WORDS8(s, 0, w)
+            store32(Kbar_ws, 32, item, w);
+        }
+    }
+    // (K', r') = G(m' || h)
+    uint32_t mm[8];
+    load32(m_ws, 32, it, mm);
+    lane_G64(s, mm, h);
+    if (item < n) {
+        MLKEM_STATE_WORDS8(s, 0, w)
+        store32(Kp_ws, 32, item, w);
+        MLKEM_STATE_WORDS8(s, 8, w)
+        store32(r_ws, 32, item, w);
+        if (status) status[item] = st;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_hash_keygen_seed — K-PKE.KeyGen's (rho, sigma) = G(d || k) (ml_kem.c:674-681)
+// ------------------------------------------------------------------------------------------------
+template <int K>
+__global__ void __launch_bounds__(WAVE) k_hash_keygen_seed(size_t n, const uint8_t* __restrict__ d, uint8_t* __restrict__ rho_ws,
+                                                           uint8_t* __restrict__ sigma_ws) {
+    const size_t item = (size_t)blockIdx.x * WAVE + lane_id();
+    const size_t it = item < n ? item : n - 1;
+    KeccakState s;
+    uint32_t dd[8], w[8];
+    load32(d, 32, it, dd);
+    keccak_zero(s);
+    MLKEM_SET_WORDS8(s, 0, dd)
+    keccak_xor_byte<32>(s, (uint32_t)K);
+    keccak_xor_byte<33>(s, 0x06);
+    keccak_xor_byte<71>(s, 0x80);
+    keccak_f1600(s);
+    if (item < n) {
+        MLKEM_STATE_WORDS8(s, 0, w)
+        store32(rho_ws, 32, item, w);
+        MLKEM_STATE_WORDS8(s, 8, w)
+        store32(sigma_ws, 32, item, w);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_hash_keygen_fin — KeyGen_internal's dk tail (ml_kem.c:1065-1077): dk[768k+32 ..] = H(ek) ; dk[768k+64 ..] = z
+// ------------------------------------------------------------------------------------------------
+template <int K>
+__global__ void __launch_bounds__(WAVE) k_hash_keygen_fin(size_t n, const uint8_t* __restrict__ ek, const uint8_t* __restrict__ z,
+                                                          uint8_t* __restrict__ dk) {
+    __shared__ uint32_t stage[STAGE_WORDS];
+    constexpr unsigned EK = 384 * K + 32, DK = 768 * K + 96;
+    const size_t item0 = (size_t)blockIdx.x * WAVE, item = item0 + lane_id();
+    KeccakState s;
+    MsgView mv{ek, EK, EK, ek, EK, 0};
+    wave_sponge_absorb<136, 0x06>(s, stage, mv, item0, n);
+    if (item < n) {
+        uint32_t w[8];
+        MLKEM_STATE_WORDS8(s, 0, w)
+        store32(dk + 768 * K + 32, DK, item, w);
+        load32(z, 32, item, w);
+        store32(dk + 768 * K + 64, DK, item, w);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_hash_batch — stand-alone H / G / J over equal-length messages (parity tests of the staged sponge)
+//   kind 0: H = SHA3-256 (32 B out), 1: G = SHA3-512 (64 B out), 2: J = SHAKE128 (32 B out)
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(WAVE) k_hash_batch(size_t n, int kind, const uint8_t* __restrict__ msg, unsigned len,
+                                                     size_t stride, uint8_t* __restrict__ out) {
+    __shared__ uint32_t stage[STAGE_WORDS];
+    const size_t item0 = (size_t)blockIdx.x * WAVE, item = item0 + lane_id();
+    KeccakState s;
+    MsgView mv{msg, stride, len, msg, stride, 0};
+    uint32_t w[8];
+    if (kind == 0) wave_sponge_absorb<136, 0x06>(s, stage, mv, item0, n);
+    else if (kind == 1) wave_sponge_absorb<72, 0x06>(s, stage, mv, item0, n);
+    else wave_sponge_absorb<168, 0x1F>(s, stage, mv, item0, n);
+    if (item < n) {
+        MLKEM_STATE_WORDS8(s, 0, w)
+        store32(out, kind == 1 ? 64 : 32, item, w);
+        if (kind == 1) {
+            MLKEM_STATE_WORDS8(s, 8, w)
+            store32(out + 32, 64, item, w);
+        }
+    }
+}
+
+// ================================================================================================
+// k_sample — lane-sliced SHAKE128 sponges.
+//   blocks [0, xof_blocks)            : XOF role, sponge g = block*64 + lane  -> SampleNTT (ml_kem.c:189-245)
+//   blocks [xof_blocks, +prf_blocks)  : PRF role, sponge g                    -> PRF bytes  (ml_kem.c:496-515)
+//
+// XOF seeds:  mode MATRIX : g -> (item, row a, col b);  seed = rho[item] || i0 || i1 with (i0, i1) = (a, b)
+//                           for Encrypt's A^T (ml_kem.c:817-823) and (b, a) for KeyGen's A (ml_kem.c:686-693);
+//                           output polynomial index g  (= item*K*K + a*K + b)
+//             mode SEEDS  : g -> explicit 34-byte seed (stand-alone SampleNTT primitive)
+// PRF seeds:  g -> (item, counter n) ; input = r[item] || n ; the first `n_eta1` counters produce 64*ETA1
+//             bytes, the rest 128 bytes; all rows are PRF_STRIDE bytes apart.
+//
+// Rejection sampling writes accepted coefficients into a per-lane LDS ring of 128 coefficients and the
+// wave flushes every completed, 128-byte aligned 64-coefficient chunk with 8 lanes x 16 B per polynomial.
+// ================================================================================================
+constexpr int RING = 128;                 // coefficients per lane ring
+constexpr int RING_STRIDE = RING + 8;     // int16 units: 272 B rows (16-byte aligned, 4-bank skew)
+
+struct SampleArgs {
+    // XOF role
+    size_t n_xof;             // number of XOF sponges
+    const uint8_t* rho;       // MATRIX: per-item 32-byte seed base ; SEEDS: 34-byte seeds
+    size_t rho_stride;
+    int K;                    // MATRIX: matrix dimension ; SEEDS: 0
+    int transpose;            // MATRIX: 1 -> seed bytes (a, b) [Encrypt], 0 -> (b, a) [KeyGen]
+    uint16_t* A;              // output polynomials [n_xof][256]
+    unsigned xof_blocks;
+    // PRF role
+    size_t n_prf;             // number of PRF sponges
+    const uint8_t* r;         // per-item 32-byte seed, stride 32 ; or (PRF primitive) 33-byte inputs
+    int per_item;             // counters per item (0 -> explicit 33-byte inputs, stride 33)
+    int n_eta1;               // counters < n_eta1 use eta1
+    int eta1;
+    uint8_t* prf;             // output rows
+    unsigned prf_stride;
+};
+
+// flush every lane-ring chunk that has become complete; ring rows live in `ring` (this wave's slice)
+__device__ __forceinline__ void ring_flush(const int16_t* ring, uint16_t* A, size_t g, size_t n_xof, int cnt, int& flushed) {
+    const int l = lane_id();
+    const int has = (cnt - flushed >= 64) && (g < n_xof);
+    if (__ballot(has) == 0) return;
+    const int grp = l >> 3, sub = l & 7;
+#pragma unroll 1
+    for (int step = 0; step < 8; step++) {
+        const int p = step * 8 + grp;                       // lane (= polynomial of this wave) being flushed
+        const int p_has = __shfl(has, p);
+        const int p_flushed = __shfl(flushed, p);
+        if (p_has) {
+            const int16_t* src = ring + p * RING_STRIDE + (p_flushed & (RING - 1)) + sub * 8;
+            uint4 v = *reinterpret_cast<const uint4*>(src);
+            const size_t gp = g - (size_t)l + (size_t)p;     // sponge index of lane p
+            *reinterpret_cast<uint4*>(A + gp * 256 + p_flushed + sub * 8) = v;
+        }
+    }
+    if (has) flushed += 64;
+}
+
+// one candidate of SampleNTT (ml_kem.c:211-219)
+#define MLKEM_CAND(d)                                                      \
+    {                                                                      \
+        const bool ok = ((d) < (unsigned)KQ) && (cnt < 256);               \
+        if (ok) myring[cnt & (RING - 1)] = (int16_t)(d);                   \
+        cnt += ok ? 1 : 0;                                                 \
+    }
+// four 3-byte groups out of three state dwords; TRIPLES limits how many of the four are consumed
+#define MLKEM_GROUP4(W0, NT)                                                                      \
+    {                                                                                             \
+        const uint32_t w0 = keccak_word<W0>(s), w1 = keccak_word<W0 + 1>(s), w2 = keccak_word<W0 + 2>(s); \
+        const uint32_t v0 = w0 & 0xFFFFFFu, v1 = (w0 >> 24) | ((w1 & 0xFFFFu) << 8);              \
+        const uint32_t v2 = (w1 >> 16) | ((w2 & 0xFFu) << 16), v3 = w2 >> 8;                      \
+        MLKEM_CAND(v0 & 0xFFFu) MLKEM_CAND(v0 >> 12)                                              \
+        MLKEM_CAND(v1 & 0xFFFu) MLKEM_CAND(v1 >> 12)                                              \
+        if (NT > 2) { MLKEM_CAND(v2 & 0xFFFu) MLKEM_CAND(v2 >> 12) }                              \
+        if (NT > 3) { MLKEM_CAND(v3 & 0xFFFu) MLKEM_CAND(v3 >> 12) }                              \
+    }
+
+__global__ void __launch_bounds__(WAVE) k_sample(SampleArgs a) {
+    __shared__ __attribute__((aligned(16))) int16_t ring[WAVE * RING_STRIDE];
+    const int l = lane_id();
+    KeccakState s;
+    if (blockIdx.x < a.xof_blocks) {
+        // ---------------- XOF role: SampleNTT ----------------
+        const size_t g = (size_t)blockIdx.x * WAVE + l;
+        const size_t gc = g < a.n_xof ? g : a.n_xof - 1;
+        uint32_t seed[8];
+        unsigned i0, i1;
+        if (a.K) {
+            const size_t kk = (size_t)(a.K * a.K), item = gc / kk;
+            const unsigned e = (unsigned)(gc - item * kk), ra = e / (unsigned)a.K, cb = e - ra * (unsigned)a.K;
+            load32(a.rho, a.rho_stride, item, seed);
+            i0 = a.transpose ? ra : cb;
+            i1 = a.transpose ? cb : ra;
+        } else {
+            const uint8_t* sp = a.rho + gc * a.rho_stride;
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+                seed[i] = (uint32_t)sp[4 * i] | ((uint32_t)sp[4 * i + 1] << 8) | ((uint32_t)sp[4 * i + 2] << 16) |
+                          ((uint32_t)sp[4 * i + 3] << 24);
+            i0 = sp[32];
+            i1 = sp[33];
+        }
+        int16_t* myring = ring + l * RING_STRIDE;
+        int cnt = 0, flushed = 0;
+        bool fresh = true;      // (re)initialise the sponge: first pass, or the reference's seed-mutation retry
+        int blk = 0;            // squeeze blocks consumed since the last (re)initialisation
+        while (true) {
+            if (fresh) {
+                keccak_zero(s);
+                MLKEM_SET_WORDS8(s, 0, seed)
+                keccak_xor_byte<32>(s, i0 & 0xFFu);
+                keccak_xor_byte<33>(s, i1 & 0xFFu);
+                keccak_xor_byte<34>(s, 0x1F);
+                keccak_xor_byte<167>(s, 0x80);
+                cnt = 0; flushed = 0; blk = 0; fresh = false;
+            }
+            keccak_f1600(s);
+            // first half of the block: triples 0..27  (dwords 0..20)
+            MLKEM_GROUP4(0, 4) MLKEM_GROUP4(3, 4) MLKEM_GROUP4(6, 4) MLKEM_GROUP4(9, 4)
+            MLKEM_GROUP4(12, 4) MLKEM_GROUP4(15, 4) MLKEM_GROUP4(18, 4)
+            wave_lds_fence();
+            ring_flush(ring, a.A, g, a.n_xof, cnt, flushed);
+            wave_lds_fence();
+            // second half: triples 28..55 (dwords 21..41); in the 5th block the reference never uses
+            // triples 278, 279 (ml_kem.c:223-227: the 279th triple only trips the iteration limit)
+            MLKEM_GROUP4(21, 4) MLKEM_GROUP4(24, 4) MLKEM_GROUP4(27, 4) MLKEM_GROUP4(30, 4)
+            MLKEM_GROUP4(33, 4) MLKEM_GROUP4(36, 4)
+            if (blk == 4) MLKEM_GROUP4(39, 2) else MLKEM_GROUP4(39, 4)
+            wave_lds_fence();
+            ring_flush(ring, a.A, g, a.n_xof, cnt, flushed);
+            wave_lds_fence();
+            blk++;
+            if (blk == 5 && cnt < 256) {   // ml_kem.c:237-242: B[32]++, B[33]++ and start over
+                i0 = (i0 + 1) & 0xFFu;
+                i1 = (i1 + 1) & 0xFFu;
+                fresh = true;
+            }
+            if (__ballot(cnt < 256) == 0) break;
+        }
+    } else {
+        // ---------------- PRF role ----------------
+        const size_t g = (size_t)(blockIdx.x - a.xof_blocks) * WAVE + l;
+        const size_t gc = g < a.n_prf ? g : a.n_prf - 1;
+        uint32_t seed[8];
+        unsigned ctr, eta;
+        if (a.per_item) {
+            const size_t item = gc / (size_t)a.per_item;
+            ctr = (unsigned)(gc - item * (size_t)a.per_item);
+            load32(a.r, 32, item, seed);
+            eta = (int)ctr < a.n_eta1 ? (unsigned)a.eta1 : 2u;
+        } else {
+            const uint8_t* sp = a.r + gc * 33;
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+                seed[i] = (uint32_t)sp[4 * i] | ((uint32_t)sp[4 * i + 1] << 8) | ((uint32_t)sp[4 * i + 2] << 16) |
+                          ((uint32_t)sp[4 * i + 3] << 24);
+            ctr = sp[32];
+            eta = (unsigned)a.eta1;
+        }
+        keccak_zero(s);
+        MLKEM_SET_WORDS8(s, 0, seed)
+        keccak_xor_byte<32>(s, ctr & 0xFFu);
+        keccak_xor_byte<33>(s, 0x1F);
+        keccak_xor_byte<167>(s, 0x80);
+        keccak_f1600(s);
+        uint32_t* out = reinterpret_cast<uint32_t*>(a.prf + gc * a.prf_stride);
+        if (g < a.n_prf) {
+#define MLKEM_OW(W) out[W] = keccak_word<W>(s);
+            MLKEM_OW(0) MLKEM_OW(1) MLKEM_OW(2) MLKEM_OW(3) MLKEM_OW(4) MLKEM_OW(5) MLKEM_OW(6) MLKEM_OW(7)
+            MLKEM_OW(8) MLKEM_OW(9) MLKEM_OW(10) MLKEM_OW(11) MLKEM_OW(12) MLKEM_OW(13) MLKEM_OW(14) MLKEM_OW(15)
+            MLKEM_OW(16) MLKEM_OW(17) MLKEM_OW(18) MLKEM_OW(19) MLKEM_OW(20) MLKEM_OW(21) MLKEM_OW(22) MLKEM_OW(23)
+            MLKEM_OW(24) MLKEM_OW(25) MLKEM_OW(26) MLKEM_OW(27) MLKEM_OW(28) MLKEM_OW(29) MLKEM_OW(30) MLKEM_OW(31)
+        }
+        if (__ballot(eta == 3) != 0) {   // eta = 3 needs 192 bytes: 168 from this block + 24 from the next
+            if (g < a.n_prf && eta == 3) {
+                MLKEM_OW(32) MLKEM_OW(33) MLKEM_OW(34) MLKEM_OW(35) MLKEM_OW(36) MLKEM_OW(37) MLKEM_OW(38) MLKEM_OW(39)
+                MLKEM_OW(40) MLKEM_OW(41)
+            }
+            keccak_f1600(s);
+            if (g < a.n_prf && eta == 3) {
+                out[42] = keccak_word<0>(s); out[43] = keccak_word<1>(s); out[44] = keccak_word<2>(s);
+                out[45] = keccak_word<3>(s); out[46] = keccak_word<4>(s); out[47] = keccak_word<5>(s);
+            }
+#undef MLKEM_OW
+        }
+    }
+}
+
+// ================================================================================================
+// wave-per-instance polynomial arithmetic
+// ================================================================================================
+constexpr int ARITH_WAVES = 4;   // waves per workgroup (each fully independent)
+
+template <int K>
+struct ArithLds {
+    __attribute__((aligned(16))) int16_t xch[256];
+    __attribute__((aligned(16))) int16_t vhat[K][256];   // NTT-domain vector (y-hat or s-hat), centred
+    __attribute__((aligned(16))) int16_t vgam[K][128];   // odd coefficient times gamma (ml_kem.c:402-403), per pair
+    uint32_t cbuf[CODEC_BUF_WORDS];
+};
+
+// keep an NTT-domain polynomial (NAT layout, centred) and its gamma-premultiplied odd coefficients in LDS
+__device__ __forceinline__ void stash_vhat(int16_t* vh, int16_t* vg, const int (&x)[4], const NttTwiddles& tw) {
+    const int l = lane_id();
+    xch_write_nat(vh, l, x);
+    const int g0 = fqmul(x[1], tw.fD), g1 = fqmul(x[3], -tw.fD);
+    *reinterpret_cast<uint32_t*>(vg + 2 * l) = ((uint32_t)g0 & 0xFFFFu) | ((uint32_t)g1 << 16);
+}
+// acc += MultiplyNTTs(a, v) (ml_kem.c:395-442) for the lane's two coefficient pairs, products left unreduced
+__device__ __forceinline__ void basemul_acc(int (&acc)[4], const int (&a)[4], const int16_t* vh, const int16_t* vg) {
+    const int l = lane_id();
+    int y[4];
+    xch_read_nat(vh, l, y);
+    const uint32_t gw = *reinterpret_cast<const uint32_t*>(vg + 2 * l);
+    const int yg0 = (int)(int16_t)(gw & 0xFFFFu), yg1 = (int)gw >> 16;
+    acc[0] += __mul24(a[0], y[0]) + __mul24(a[1], yg0);
+    acc[1] += __mul24(a[0], y[1]) + __mul24(a[1], y[0]);
+    acc[2] += __mul24(a[2], y[2]) + __mul24(a[3], yg1);
+    acc[3] += __mul24(a[2], y[3]) + __mul24(a[3], y[2]);
+}
+// load the lane's 4 coefficients of a uint16 polynomial in HBM (8 bytes per lane, 512 B per wave)
+__device__ __forceinline__ void load_poly_nat(const uint16_t* p, int (&x)[4]) {
+    uint2 v = *reinterpret_cast<const uint2*>(p + 4 * lane_id());
+    x[0] = (int)(v.x & 0xFFFFu); x[1] = (int)(v.x >> 16);
+    x[2] = (int)(v.y & 0xFFFFu); x[3] = (int)(v.y >> 16);
+}
+__device__ __forceinline__ void store_poly_nat(uint16_t* p, const int (&x)[4]) {
+    uint2 v;
+    v.x = ((uint32_t)x[0] & 0xFFFFu) | ((uint32_t)x[1] << 16);
+    v.y = ((uint32_t)x[2] & 0xFFFFu) | ((uint32_t)x[3] << 16);
+    *reinterpret_cast<uint2*>(p + 4 * lane_id()) = v;
+}
+
+// Compress_D + ByteEncode_D of a canonical polynomial, then either store the bytes or compare with `ref`
+template <int D, bool COMPARE>
+__device__ __forceinline__ uint32_t emit_compressed(uint32_t* cbuf, const int (&x)[4], uint8_t* out, const uint8_t* ref) {
+    unsigned v[4];
+#pragma unroll
+    for (int m = 0; m < 4; m++) v[m] = compress_d<D>((unsigned)x[m]);
+    codec_zero<D>(cbuf);
+    wave_lds_fence();
+    codec_encode<D>(cbuf, v);
+    wave_lds_fence();
+    uint32_t diff = 0;
+    if constexpr (COMPARE) diff = codec_diff_bytes<D>(cbuf, ref);
+    else codec_store_bytes<D>(cbuf, out);
+    wave_lds_fence();
+    return diff;
+}
+// ByteEncode_12 of a canonical polynomial (ml_kem.c:736-756) to one or two destinations
+__device__ __forceinline__ void emit_encode12(uint32_t* cbuf, const int (&x)[4], uint8_t* out0, uint8_t* out1) {
+    unsigned v[4];
+#pragma unroll
+    for (int m = 0; m < 4; m++) v[m] = (unsigned)x[m];
+    codec_zero<12>(cbuf);
+    wave_lds_fence();
+    codec_encode<12>(cbuf, v);
+    wave_lds_fence();
+    codec_store_bytes<12>(cbuf, out0);
+    if (out1) codec_store_bytes<12>(cbuf, out1);
+    wave_lds_fence();
+}
+// ByteDecode_D (+ optional Decompress_D) of 32*D bytes in HBM into the lane's 4 coefficients
+template <int D, bool DECOMPRESS>
+__device__ __forceinline__ void fetch_decoded(uint32_t* cbuf, const uint8_t* src, int (&x)[4]) {
+    unsigned v[4];
+    codec_load_bytes<D>(cbuf, src);
+    wave_lds_fence();
+    codec_decode<D>(cbuf, v);
+    wave_lds_fence();
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+        if constexpr (DECOMPRESS) x[m] = (int)decompress_d<D>(v[m]);
+        else x[m] = (int)v[m];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_encrypt — K-PKE.Encrypt (ml_kem.c:776-936) given A^T (k_sample, XOF role) and the PRF bytes (PRF role).
+//   COMPARE = false : write c                                   (Encaps_internal, ml_kem.c:1127)
+//   COMPARE = true  : compare c' with c, K = (c == c') ? K' : Kbar (Decaps_internal, ml_kem.c:1206-1215)
+// ------------------------------------------------------------------------------------------------
+template <int K, int ETA1, int DU, int DV, bool COMPARE>
+__global__ void __launch_bounds__(WAVE * ARITH_WAVES) k_encrypt(size_t n, const uint8_t* __restrict__ ek, size_t ek_stride,
+                                                                const uint8_t* __restrict__ msg, const uint16_t* __restrict__ A,
+                                                                const uint8_t* __restrict__ prf, uint8_t* __restrict__ c_out,
+                                                                const uint8_t* __restrict__ c_in, const uint8_t* __restrict__ Kp,
+                                                                const uint8_t* __restrict__ Kbar, uint8_t* __restrict__ Kout) {
+    __shared__ ArithLds<K> lds_all[ARITH_WAVES];
+    const int wv = (int)(threadIdx.x >> 6), l = lane_id();
+    const size_t item = (size_t)blockIdx.x * ARITH_WAVES + wv;
+    if (item >= n) return;
+    ArithLds<K>& L = lds_all[wv];
+    constexpr unsigned PS = (ETA1 == 3) ? 192 : 128, CLEN = 32 * (DU * K + DV);
+    NttTwiddles tw;
+    load_twiddles(tw);
+    const uint8_t* my_prf = prf + item * (size_t)((2 * K + 1) * PS);
+    const uint8_t* my_ek = ek + item * ek_stride;
+    const uint16_t* my_A = A + item * (size_t)(K * K * 256);
+    uint8_t* my_c = COMPARE ? nullptr : c_out + item * CLEN;
+    const uint8_t* my_cin = COMPARE ? c_in + item * CLEN : nullptr;
+    uint32_t diff = 0;
+    int x[4];
+    // y-hat = NTT(CBD_eta1(PRF(r, n)))  n = 0..K-1   (ml_kem.c:826-836)
+#pragma unroll
+    for (int b = 0; b < K; b++) {
+        cbd_nat<ETA1>(my_prf + b * PS, x);
+        wave_ntt(x, L.xch, tw);
+#pragma unroll
+        for (int m = 0; m < 4; m++) x[m] = barrett16(x[m]);
+        stash_vhat(L.vhat[b], L.vgam[b], x, tw);
+    }
+    wave_lds_fence();
+    // u[a] = InverseNTT(sum_b A^T[a][b] o y-hat[b]) + e1[a]  ->  Compress_du, ByteEncode_du   (ml_kem.c:854-896)
+#pragma unroll 1
+    for (int a = 0; a < K; a++) {
+        int acc[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int b = 0; b < K; b++) {
+            int av[4];
+            load_poly_nat(my_A + (a * K + b) * 256, av);
+            basemul_acc(acc, av, L.vhat[b], L.vgam[b]);
+        }
+#pragma unroll
+        for (int m = 0; m < 4; m++) x[m] = mont_reduce(acc[m]);
+        wave_intt(x, L.xch, tw, INTT_FINAL_DEMONT);
+        int e[4];
+        cbd_nat<2>(my_prf + (K + a) * PS, e);
+#pragma unroll
+        for (int m = 0; m < 4; m++) x[m] = canon16(x[m] + e[m]);
+        diff |= emit_compressed<DU, COMPARE>(L.cbuf, x, COMPARE ? nullptr : my_c + a * 32 * DU,
+                                             COMPARE ? my_cin + a * 32 * DU : nullptr);
+    }
+    // v = InverseNTT(t-hat . y-hat) + e2 + Decompress_1(m)  ->  Compress_dv, ByteEncode_dv   (ml_kem.c:867-904)
+    {
+        int acc[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int b = 0; b < K; b++) {
+            int tv[4];
+            fetch_decoded<12, false>(L.cbuf, my_ek + 384 * b, tv);   // raw 12-bit values, no mod q (F3)
+            basemul_acc(acc, tv, L.vhat[b], L.vgam[b]);
+        }
+#pragma unroll
+        for (int m = 0; m < 4; m++) x[m] = mont_reduce(acc[m]);
+        wave_intt(x, L.xch, tw, INTT_FINAL_DEMONT);
+        int e[4];
+        cbd_nat<2>(my_prf + (2 * K) * PS, e);
+        const unsigned mb = msg[item * 32 + (l >> 1)] >> (4 * (l & 1));   // the lane's 4 message bits
+#pragma unroll
+        for (int m = 0; m < 4; m++) x[m] = canon16(x[m] + e[m] + (int)(((mb >> m) & 1u) * 1665u));
+        diff |= emit_compressed<DV, COMPARE>(L.cbuf, x, COMPARE ? nullptr : my_c + K * 32 * DU,
+                                             COMPARE ? my_cin + K * 32 * DU : nullptr);
+    }
+    if constexpr (COMPARE) {
+        const bool mismatch = __ballot(diff != 0) != 0;
+        if (l < 8) {
+            const uint32_t* src = reinterpret_cast<const uint32_t*>((mismatch ? Kbar : Kp) + item * 32);
+            reinterpret_cast<uint32_t*>(Kout + item * 32)[l] = src[l];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_decrypt — K-PKE.Decrypt (ml_kem.c:942-1023): m' = ByteEncode_1(Compress_1(v - InverseNTT(s-hat . NTT(u))))
+// ------------------------------------------------------------------------------------------------
+template <int K, int DU, int DV>
+__global__ void __launch_bounds__(WAVE * ARITH_WAVES) k_decrypt(size_t n, const uint8_t* __restrict__ dk, size_t dk_stride,
+                                                                const uint8_t* __restrict__ c, uint8_t* __restrict__ m_out) {
+    __shared__ ArithLds<1> lds_all[ARITH_WAVES];
+    const int wv = (int)(threadIdx.x >> 6), l = lane_id();
+    const size_t item = (size_t)blockIdx.x * ARITH_WAVES + wv;
+    if (item >= n) return;
+    ArithLds<1>& L = lds_all[wv];
+    constexpr unsigned CLEN = 32 * (DU * K + DV);
+    NttTwiddles tw;
+    load_twiddles(tw);
+    const uint8_t* my_c = c + item * CLEN;
+    const uint8_t* my_dk = dk + item * dk_stride;
+    int acc[4] = {0, 0, 0, 0}, x[4];
+#pragma unroll 1
+    for (int b = 0; b < K; b++) {
+        fetch_decoded<DU, true>(L.cbuf, my_c + b * 32 * DU, x);          // u[b] (ml_kem.c:978-987)
+        wave_ntt(x, L.xch, tw);
+#pragma unroll
+        for (int m = 0; m < 4; m++) x[m] = barrett16(x[m]);
+        stash_vhat(L.vhat[0], L.vgam[0], x, tw);
+        wave_lds_fence();
+        int sv[4];
+        fetch_decoded<12, false>(L.cbuf, my_dk + 384 * b, sv);            // s-hat[b] (ml_kem.c:996-998)
+        basemul_acc(acc, sv, L.vhat[0], L.vgam[0]);
+        wave_lds_fence();
+    }
+#pragma unroll
+    for (int m = 0; m < 4; m++) x[m] = mont_reduce(acc[m]);
+    wave_intt(x, L.xch, tw, INTT_FINAL_DEMONT);
+    int v[4];
+    fetch_decoded<DV, true>(L.cbuf, my_c + K * 32 * DU, v);              // v (ml_kem.c:990-993)
+    unsigned bits = 0;
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+        const int w = canon16(v[m] - x[m]);                              // ml_kem.c:1003
+        bits |= compress_d<1>((unsigned)w) << m;                         // ml_kem.c:1009-1011
+    }
+    // ByteEncode_1: lane l owns nibble l of the 32-byte message
+    const unsigned other = (unsigned)__shfl_xor((int)bits, 1);
+    if ((l & 1) == 0) m_out[item * 32 + (l >> 1)] = (uint8_t)(bits | (other << 4));
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_keygen — K-PKE.KeyGen after G and sampling (ml_kem.c:696-756) + the parts of KeyGen_internal that are
+// plain copies (ml_kem.c:1054-1062): ek = Enc12(t-hat) || rho ; dk = Enc12(s-hat) || ek || [H(ek)] || [z]
+// ------------------------------------------------------------------------------------------------
+template <int K, int ETA1>
+__global__ void __launch_bounds__(WAVE * ARITH_WAVES) k_keygen(size_t n, const uint16_t* __restrict__ A, const uint8_t* __restrict__ prf,
+                                                               const uint8_t* __restrict__ rho, uint8_t* __restrict__ ek,
+                                                               uint8_t* __restrict__ dk) {
+    __shared__ ArithLds<K> lds_all[ARITH_WAVES];
+    const int wv = (int)(threadIdx.x >> 6), l = lane_id();
+    const size_t item = (size_t)blockIdx.x * ARITH_WAVES + wv;
+    if (item >= n) return;
+    ArithLds<K>& L = lds_all[wv];
+    constexpr unsigned PS = (ETA1 == 3) ? 192 : 128, EK = 384 * K + 32, DK = 768 * K + 96;
+    NttTwiddles tw;
+    load_twiddles(tw);
+    const uint8_t* my_prf = prf + item * (size_t)(2 * K * PS);
+    const uint16_t* my_A = A + item * (size_t)(K * K * 256);
+    uint8_t* my_ek = ek + item * EK;
+    uint8_t* my_dk = dk + item * DK;
+    int x[4];
+    // s-hat (ml_kem.c:696-706), dk_pke = ByteEncode_12(s-hat) (ml_kem.c:750-756)
+#pragma unroll 1
+    for (int b = 0; b < K; b++) {
+        cbd_nat<ETA1>(my_prf + b * PS, x);
+        wave_ntt(x, L.xch, tw);
+        int cx[4];
+#pragma unroll
+        for (int m = 0; m < 4; m++) { x[m] = barrett16(x[m]); cx[m] = x[m] + ((x[m] >> 31) & KQ); }
+        stash_vhat(L.vhat[b], L.vgam[b], x, tw);
+        emit_encode12(L.cbuf, cx, my_dk + 384 * b, nullptr);
+    }
+    wave_lds_fence();
+    // t-hat[a] = sum_b A[a][b] o s-hat[b] + e-hat[a] (ml_kem.c:710-727), ek = ByteEncode_12(t-hat) || rho
+#pragma unroll 1
+    for (int a = 0; a < K; a++) {
+        int acc[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int b = 0; b < K; b++) {
+            int av[4];
+            load_poly_nat(my_A + (a * K + b) * 256, av);
+            basemul_acc(acc, av, L.vhat[b], L.vgam[b]);
+        }
+        int e[4];
+        cbd_nat<ETA1>(my_prf + (K + a) * PS, e);
+        wave_ntt(e, L.xch, tw);
+        int t[4];
+#pragma unroll
+        for (int m = 0; m < 4; m++) t[m] = canon16(fqmul(mont_reduce(acc[m]), MONT2) + barrett16(e[m]));
+        emit_encode12(L.cbuf, t, my_ek + 384 * a, my_dk + 384 * K + 384 * a);
+    }
+    if (l < 8) {
+        const uint32_t r = reinterpret_cast<const uint32_t*>(rho + item * 32)[l];
+        reinterpret_cast<uint32_t*>(my_ek + 384 * K)[l] = r;
+        reinterpret_cast<uint32_t*>(my_dk + 768 * K)[l] = r;
+    }
+}
+
+// ================================================================================================
+// stand-alone primitives (C-ABI: mlkem_ntt / mlkem_intt / mlkem_multiply_ntts / mlkem_sample_cbd)
+// ================================================================================================
+// One polynomial per wave, grid-stride.  In/out uint16, canonical output (ml_kem.c:287 / :336).
+template <bool INVERSE>
+__global__ void __launch_bounds__(WAVE * ARITH_WAVES) k_ntt_batch(size_t n, const uint16_t* __restrict__ in, uint16_t* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) int16_t xch_all[ARITH_WAVES][256];
+    const int wv = (int)(threadIdx.x >> 6);
+    NttTwiddles tw;
+    load_twiddles(tw);
+    const size_t stride = (size_t)gridDim.x * ARITH_WAVES;
+    for (size_t p = (size_t)blockIdx.x * ARITH_WAVES + wv; p < n; p += stride) {
+        int x[4];
+        load_poly_nat(in + p * 256, x);
+#pragma unroll
+        for (int m = 0; m < 4; m++) x[m] &= 0xFFF;   // 12-bit fields of the reference's union integer
+        if constexpr (INVERSE) wave_intt(x, xch_all[wv], tw, INTT_FINAL_PLAIN);
+        else wave_ntt(x, xch_all[wv], tw);
+#pragma unroll
+        for (int m = 0; m < 4; m++) x[m] = canon16(x[m]);
+        store_poly_nat(out + p * 256, x);
+    }
+}
+
+// MultiplyNTTs (ml_kem.c:415-442): h = a o b, one polynomial pair per wave
+__global__ void __launch_bounds__(WAVE * ARITH_WAVES) k_basemul_batch(size_t n, const uint16_t* __restrict__ a, const uint16_t* __restrict__ b,
+                                                                      uint16_t* __restrict__ h) {
+    __shared__ __attribute__((aligned(16))) int16_t vh_all[ARITH_WAVES][256];
+    __shared__ __attribute__((aligned(16))) int16_t vg_all[ARITH_WAVES][128];
+    const int wv = (int)(threadIdx.x >> 6);
+    NttTwiddles tw;
+    load_twiddles(tw);
+    const size_t stride = (size_t)gridDim.x * ARITH_WAVES;
+    for (size_t p = (size_t)blockIdx.x * ARITH_WAVES + wv; p < n; p += stride) {
+        int av[4], bv[4], acc[4] = {0, 0, 0, 0};
+        load_poly_nat(a + p * 256, av);
+        load_poly_nat(b + p * 256, bv);
+#pragma unroll
+        for (int m = 0; m < 4; m++) { av[m] &= 0xFFF; bv[m] = barrett16(bv[m] & 0xFFF); }
+        stash_vhat(vh_all[wv], vg_all[wv], bv, tw);
+        wave_lds_fence();
+        basemul_acc(acc, av, vh_all[wv], vg_all[wv]);
+        wave_lds_fence();
+#pragma unroll
+        for (int m = 0; m < 4; m++) av[m] = canon16(fqmul(mont_reduce(acc[m]), MONT2));
+        store_poly_nat(h + p * 256, av);
+    }
+}
+
+// SamplePolyCBD (ml_kem.c:253-275): bytes [n][64*eta] -> canonical uint16 polynomials
+template <int ETA>
+__global__ void __launch_bounds__(WAVE * ARITH_WAVES) k_cbd_batch(size_t n, const uint8_t* __restrict__ bytes, uint16_t* __restrict__ out) {
+    const int wv = (int)(threadIdx.x >> 6);
+    const size_t stride = (size_t)gridDim.x * ARITH_WAVES;
+    for (size_t p = (size_t)blockIdx.x * ARITH_WAVES + wv; p < n; p += stride) {
+        int x[4];
+        cbd_nat<ETA>(bytes + p * 64 * ETA, x);
+#pragma unroll
+        for (int m = 0; m < 4; m++) x[m] += (x[m] >> 31) & KQ;
+        store_poly_nat(out + p * 256, x);
+    }
+}
+
+}   // namespace mlkem

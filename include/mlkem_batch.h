@@ -1,0 +1,112 @@
+/*
+ * mlkem_batch.h — C-ABI of libmlkem_amd.so, the MI355X (gfx950) batched ML-KEM engine.
+ *
+ * This is the drop-in boundary for the hot path of rsjahnige/CRYSTALS-Kyber: every entry point is
+ * `extern "C"`, takes plain pointers + sizes, and names the reference interface it replaces.  All byte
+ * strings are PACKED uint8 (one byte per byte — not the reference's 4-byte `union byte`, SURVEY.md F1;
+ * the ml_kem.h-compatible shim in mlkem_compat.h widens/narrows at its edge), polynomials are uint16[256]
+ * with coefficients in [0, q), item i of a batch lives at base + i * item_size.
+ *
+ * Results are bit-identical to the reference's ml_kem.c on the same inputs, including its deviations
+ * from FIPS 203: PRF and J are SHAKE128 (ml_kem.c:508, :546) and ByteDecode_12 performs no reduction, so
+ * the Encaps modulus check never fires (ml_kem.c:170, :1273-1291).
+ *
+ * Two families:
+ *   *_dev : pointers are DEVICE pointers (HBM resident), the work is enqueued on `stream` (a hipStream_t
+ *           passed as void*; NULL = default stream) and the call returns without synchronising.
+ *           Base pointers must be 16-byte aligned.
+ *   plain : pointers are HOST pointers; the call stages through device memory, runs the *_dev path and
+ *           synchronises before returning.
+ * There is no CPU fallback: without a usable HIP device every call returns MLKEM_ERR_NO_DEVICE.
+ *
+ * Return value: 0 on success, negative MLKEM_ERR_* otherwise.  Per-item conditions (the reference's
+ * ml_errno = -5 hash-check failure) are reported through the `status` array, never through a global.
+ */
+#ifndef MLKEM_BATCH_H
+#define MLKEM_BATCH_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MLKEM_OK 0
+#define MLKEM_ERR_PARAM_SET (-1)    /* unknown parameter set   (reference: ml_errno = -1, ml_kem.c:1389-1391) */
+#define MLKEM_ERR_RNG (-2)          /* entropy source failed   (reference: ml_errno = -2, ml_kem.c:1243, :1297) */
+#define MLKEM_ERR_LENGTH (-3)       /* ek/dk/c length mismatch (reference: ml_errno = -3, ml_kem.c:1269, :1323, :1331) */
+#define MLKEM_ERR_MODULUS (-4)      /* never produced: the reference's check is a no-op (ml_kem.c:1273-1291) */
+#define MLKEM_ERR_HASH (-5)         /* per-item status: H(dk.ek) != dk.h (reference: ml_errno = -5, ml_kem.c:1347) */
+#define MLKEM_ERR_NO_DEVICE (-100)  /* no HIP device / HIP runtime error */
+#define MLKEM_ERR_ARG (-101)        /* NULL or misaligned pointer, bad argument */
+#define MLKEM_ERR_ALLOC (-102)      /* device or host allocation failed */
+
+/* Lengths of ek / dk / c for a parameter set in {512, 768, 1024} (ml_kem.h:52-59, ml_kem.c:1363-1395). */
+int mlkem_sizes(int param_set, unsigned* ek_len, unsigned* dk_len, unsigned* c_len);
+/* (k, eta1, eta2, du, dv) as the reference's init() fills struct PARAMS (ml_kem.c:1363-1395). */
+int mlkem_params(int param_set, int out_k_eta1_eta2_du_dv[5]);
+/* Number of visible HIP devices (0 when none / runtime unusable). */
+int mlkem_device_count(void);
+/* Text for an MLKEM_ERR_* code. */
+const char* mlkem_strerror(int code);
+/* Last HIP runtime error string seen by this thread's calls ("" if none). */
+const char* mlkem_last_hip_error(void);
+
+/* ---- engine context: owns the scratch HBM of one device --------------------------------------------- */
+typedef struct mlkem_ctx mlkem_ctx;
+/* `chunk_items` = items processed per kernel sequence (0 = default 2^20); scratch is
+ * ~10 KiB x chunk_items, allocated once here so that no *_dev call allocates. */
+int mlkem_ctx_create(mlkem_ctx** out, int device, size_t chunk_items);
+void mlkem_ctx_destroy(mlkem_ctx* ctx);
+size_t mlkem_ctx_scratch_bytes(const mlkem_ctx* ctx);
+
+/* ---- batched KEM, device pointers ----------------------------------------------------------------- */
+/* replaces KeyGen_internal(params, d, z)          ml_kem.c:1034-1084   (d, z : n x 32 ; ek : n x ek_len ; dk : n x dk_len) */
+int mlkem_keygen_dev(mlkem_ctx* ctx, int param_set, size_t n, const uint8_t* d, const uint8_t* z, uint8_t* ek, uint8_t* dk,
+                     void* stream);
+/* replaces Encaps_internal(params, ek, m)         ml_kem.c:1093-1130   (m : n x 32 ; c : n x c_len ; K : n x 32) */
+int mlkem_encaps_dev(mlkem_ctx* ctx, int param_set, size_t n, const uint8_t* ek, const uint8_t* m, uint8_t* c, uint8_t* K,
+                     void* stream);
+/* replaces KEM_Decaps(params, dk, dk_len, c, c_len) ml_kem.c:1310-1359 incl. the dk hash check:
+ *   status[i] = 0, or MLKEM_ERR_HASH when H(dk[384k : 768k+32]) != dk[768k+32 : 768k+64]
+ *   K[i]      = Decaps_internal(dk_i, c_i) (ml_kem.c:1136-1225) — for status -5 the reference returns NULL;
+ *               K[i] then holds the value Decaps_internal would have produced.
+ * `status` may be NULL (check skipped = Decaps_internal semantics). */
+int mlkem_decaps_dev(mlkem_ctx* ctx, int param_set, size_t n, const uint8_t* dk, const uint8_t* c, uint8_t* K, int32_t* status,
+                     void* stream);
+
+/* ---- batched primitives, device pointers (BASELINE config 2 and component parity tests) ------------ */
+/* replaces NTT(f)              ml_kem.c:287-329 ; in/out : n x uint16[256], coefficients in [0, q) */
+int mlkem_ntt_dev(mlkem_ctx* ctx, size_t n, const uint16_t* f, uint16_t* f_hat, void* stream);
+/* replaces InverseNTT(fh)      ml_kem.c:336-384 */
+int mlkem_intt_dev(mlkem_ctx* ctx, size_t n, const uint16_t* f_hat, uint16_t* f, void* stream);
+/* replaces MultiplyNTTs(f, g)  ml_kem.c:415-442 ; inputs may be any 12-bit value (as ByteDecode_12 yields) */
+int mlkem_multiply_ntts_dev(mlkem_ctx* ctx, size_t n, const uint16_t* f_hat, const uint16_t* g_hat, uint16_t* h_hat, void* stream);
+/* replaces SampleNTT(B)        ml_kem.c:189-245 ; seeds : n x 34 bytes (packed) */
+int mlkem_sample_ntt_dev(mlkem_ctx* ctx, size_t n, const uint8_t* seeds34, uint16_t* a_hat, void* stream);
+/* replaces SamplePolyCBD(B, eta) ml_kem.c:253-275 ; bytes : n x 64*eta */
+int mlkem_sample_cbd_dev(mlkem_ctx* ctx, int eta, size_t n, const uint8_t* bytes, uint16_t* f, void* stream);
+/* replaces PRF(s, b, eta)      ml_kem.c:496-515 (SHAKE128!) ; in : n x 33 bytes (s || b) ; out : n x 64*eta */
+int mlkem_prf_dev(mlkem_ctx* ctx, int eta, size_t n, const uint8_t* in33, uint8_t* out, void* stream);
+/* replaces H / G / J           ml_kem.c:521-572 on n equal-length messages; message i starts at
+ * msg + i*stride (stride % 4 == 0, stride >= len).  kind: 0 = H (32 B out), 1 = G (64 B), 2 = J (32 B, SHAKE128) */
+int mlkem_hash_dev(mlkem_ctx* ctx, int kind, size_t n, const uint8_t* msg, unsigned len, size_t stride, uint8_t* out, void* stream);
+
+/* ---- batched KEM, host pointers (stage + run + synchronise) ---------------------------------------- */
+int mlkem_keygen(int param_set, size_t n, const uint8_t* d, const uint8_t* z, uint8_t* ek, uint8_t* dk);
+int mlkem_encaps(int param_set, size_t n, const uint8_t* ek, const uint8_t* m, uint8_t* c, uint8_t* K);
+int mlkem_decaps(int param_set, size_t n, const uint8_t* dk, const uint8_t* c, uint8_t* K, int32_t* status);
+int mlkem_ntt(size_t n, const uint16_t* f, uint16_t* f_hat);
+int mlkem_intt(size_t n, const uint16_t* f_hat, uint16_t* f);
+
+/* ---- randomised wrappers: seeds drawn on the host with getrandom(2) ---------------- */
+/* replaces KEM_KeyGen(params)  ml_kem.c:1233-1252 for n key pairs */
+int mlkem_keygen_random(int param_set, size_t n, uint8_t* ek, uint8_t* dk);
+/* replaces KEM_Encaps(params, ek, ek_len) ml_kem.c:1257-1305 for n encapsulations; ek_len is checked (-3) */
+int mlkem_encaps_random(int param_set, size_t n, const uint8_t* ek, unsigned ek_len, uint8_t* c, uint8_t* K);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

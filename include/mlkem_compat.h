@@ -1,0 +1,62 @@
+/*
+ * mlkem_compat.h — ABI declarations of the ml_kem.h-compatible drop-in shim (libml_kem.so).
+ *
+ * A program written against the reference's ml_kem.h (rsjahnige/CRYSTALS-Kyber) keeps including the
+ * reference's own header and simply links libml_kem.so instead of ml_kem.o + sha3.o; this header only
+ * restates the binary interface the shim implements so that the shim and its tests compile without the
+ * reference tree:
+ *
+ *   symbol        reference declaration      replaced definition
+ *   ml_errno      ml_kem.h:26                ml_kem.c:16
+ *   init          ml_kem.h:94                ml_kem.c:1363-1395
+ *   KEM_KeyGen    ml_kem.h:68                ml_kem.c:1233-1252
+ *   KEM_Encaps    ml_kem.h:76                ml_kem.c:1257-1305
+ *   KEM_Decaps    ml_kem.h:83                ml_kem.c:1310-1359
+ *
+ * Layout facts that matter: the "byte" cell is a union of unsigned-int bit-fields and is
+ * therefore 4 bytes wide, value in bits 0-7, upper 24 bits undefined on input (the shim never reads them)
+ * and zero on output.  sizeof(struct PARAMS) = 20, sizeof(struct PKE) = 24, sizeof(struct KEM) = 144.
+ * Every returned array is malloc()ed by the callee and free()d by the caller, as in the reference.
+ */
+#ifndef MLKEM_COMPAT_H
+#define MLKEM_COMPAT_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+extern int ml_errno;
+
+union byte {
+    unsigned int s : 7;
+    unsigned int e : 8;
+};
+
+struct PARAMS {
+    union byte k, n1, n2, du, dv;
+};
+
+struct PKE {
+    union byte* ek;
+    union byte* dk;
+    unsigned int ek_len, dk_len;
+};
+
+struct KEM {
+    union byte K[32];
+    union byte* c;
+    unsigned int c_len;
+};
+
+enum ML_KEM { ML_KEM_512 = 512, ML_KEM_768 = 768, ML_KEM_1024 = 1024 };
+
+const struct PARAMS init(enum ML_KEM param_set);
+struct PKE KEM_KeyGen(const struct PARAMS* params);
+struct KEM KEM_Encaps(const struct PARAMS* params, const union byte* ek, unsigned int ek_len);
+union byte* KEM_Decaps(const struct PARAMS* params, const union byte* dk, unsigned int dk_len, const union byte* c,
+                       unsigned int c_len);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,125 @@
+"""CPU tier: the C-ABI libraries load and export every symbol include/*.h declares (no compute calls),
+and host-side logic that needs no GPU."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+import __graft_entry__ as ge
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    return ge.build()
+
+
+def test_batch_header_symbols_exported(pkg):
+    hdr = open(os.path.join(ROOT, "include", "mlkem_batch.h")).read()
+    declared = set(re.findall(r"\b(mlkem_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(pkg.ABI_SYMBOLS), declared ^ set(pkg.ABI_SYMBOLS)
+    lib = C.CDLL(pkg.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), name
+
+
+def test_shim_symbols_exported(pkg):
+    lib = C.CDLL(pkg.SHIM_PATH)
+    for name in pkg.SHIM_SYMBOLS:
+        assert hasattr(lib, name), name
+    assert C.c_int.in_dll(lib, "ml_errno").value == 0
+
+
+def test_sizes_and_params_match_reference_init(pkg, golden):
+    lib = pkg.load_library()
+    for pset, (ekl, dkl, cl) in pkg.SIZES.items():
+        a, b, c = C.c_uint(), C.c_uint(), C.c_uint()
+        assert lib.mlkem_sizes(pset, C.byref(a), C.byref(b), C.byref(c)) == 0
+        assert (a.value, b.value, c.value) == (ekl, dkl, cl)
+        v = (C.c_int * 5)()
+        assert lib.mlkem_params(pset, v) == 0
+        k = v[0]
+        assert ekl == 384 * k + 32 and dkl == 768 * k + 96 and cl == 32 * (v[3] * k + v[4])
+    assert list((lambda v: (lib.mlkem_params(512, v), list(v))[1])((C.c_int * 5)())) == [2, 3, 2, 10, 4]
+    assert list((lambda v: (lib.mlkem_params(768, v), list(v))[1])((C.c_int * 5)())) == [3, 2, 2, 10, 4]
+    assert list((lambda v: (lib.mlkem_params(1024, v), list(v))[1])((C.c_int * 5)())) == [4, 2, 2, 11, 5]
+    # invalid parameter sets: same code as the reference's init() (golden G7)
+    for s, rc in golden["G7_init_errno"].items():
+        assert lib.mlkem_sizes(int(s), None, None, None) == rc
+
+
+def test_shim_struct_layout_matches_reference_abi(pkg):
+    """union byte is 4 bytes; sizeof(PARAMS)=20, PKE=24, KEM=144 (K at 0, c at 128, c_len at 136)."""
+    class Byte(C.Union):
+        _fields_ = [("s", C.c_uint, 7), ("e", C.c_uint, 8)]
+
+    class PARAMS(C.Structure):
+        _fields_ = [(n, Byte) for n in ("k", "n1", "n2", "du", "dv")]
+
+    class PKE(C.Structure):
+        _fields_ = [("ek", C.POINTER(Byte)), ("dk", C.POINTER(Byte)), ("ek_len", C.c_uint), ("dk_len", C.c_uint)]
+
+    class KEM(C.Structure):
+        _fields_ = [("K", Byte * 32), ("c", C.POINTER(Byte)), ("c_len", C.c_uint)]
+
+    assert C.sizeof(Byte) == 4 and C.sizeof(PARAMS) == 20 and C.sizeof(PKE) == 24 and C.sizeof(KEM) == 144
+    assert KEM.c.offset == 128 and KEM.c_len.offset == 136
+
+    # libffi cannot pass bit-field unions by value, so the calls below use layout-identical plain-uint structs
+    class RawParams(C.Structure):
+        _fields_ = [(n, C.c_uint) for n in ("k", "n1", "n2", "du", "dv")]
+
+    class RawKEM(C.Structure):
+        _fields_ = [("K", C.c_uint * 32), ("c", C.POINTER(C.c_uint)), ("c_len", C.c_uint)]
+
+    assert C.sizeof(RawParams) == C.sizeof(PARAMS) and C.sizeof(RawKEM) == C.sizeof(KEM)
+    shim = C.CDLL(pkg.SHIM_PATH)
+    shim.init.restype = RawParams
+    p = shim.init(768)
+    assert (p.k & 0xFF, p.n1 & 0xFF, p.n2 & 0xFF, p.du & 0xFF, p.dv & 0xFF) == (3, 2, 2, 10, 4)
+    errno = C.c_int.in_dll(shim, "ml_errno")
+    assert errno.value == 0
+    shim.init(123)
+    assert errno.value == -1   # ml_kem.c:1389-1391
+    errno.value = 0
+    # length checks happen before any device work (ml_kem.c:1267, :1320, :1328)
+    shim.KEM_Encaps.restype = RawKEM
+    shim.KEM_Encaps.argtypes = [C.POINTER(RawParams), C.POINTER(C.c_uint), C.c_uint]
+    buf = (C.c_uint * 4000)()
+    r = shim.KEM_Encaps(C.byref(p), buf, 1)   # EncapsDecaps_test.c passes ek_len = 1
+    assert errno.value == -3 and not r.c and r.c_len == 0
+    errno.value = 0
+    shim.KEM_Decaps.restype = C.POINTER(C.c_uint)
+    shim.KEM_Decaps.argtypes = [C.POINTER(RawParams), C.POINTER(C.c_uint), C.c_uint, C.POINTER(C.c_uint), C.c_uint]
+    assert not shim.KEM_Decaps(C.byref(p), buf, 2400, buf, 1087) and errno.value == -3
+    errno.value = 0
+    assert not shim.KEM_Decaps(C.byref(p), buf, 2399, buf, 1088) and errno.value == -3
+    errno.value = 0
+
+
+def test_engine_fails_loudly_without_gpu(pkg):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(pkg.MLKEMError) as e:
+        pkg.MLKEM(768)
+    assert e.value.code == -100
+    lib = pkg.load_library()
+    assert lib.mlkem_device_count() == 0
+    import numpy as np
+    d = np.zeros(32, np.uint8)
+    ek = np.zeros(1184, np.uint8)
+    dk = np.zeros(2400, np.uint8)
+    rc = lib.mlkem_keygen(768, 1, d.ctypes.data, d.ctypes.data, ek.ctypes.data, dk.ctypes.data)
+    assert rc == -100 and not ek.any()   # no CPU fallback: nothing was computed
+
+
+def test_shard_range(pkg):
+    for n, w in ((1 << 23, 8), (1000, 3), (5, 8), (0, 2)):
+        spans = [pkg.shard_range(n, r, w) for r in range(w)]
+        assert spans[0][0] == 0 and spans[-1][1] == n
+        assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
+        assert max(b - a for a, b in spans) - min(b - a for a, b in spans) <= 1
+    assert pkg.shard_range(1 << 23, 3, 8) == (3 << 20, 4 << 20)   # config 5: item i -> GPU i >> 20

@@ -1,0 +1,103 @@
+"""CPU tier: the PRODUCT's kernel source (crystals-kyber_amd/csrc/mlkem_kernels.hpp + pipeline) compiled for
+the host wave emulator (tests/emu) and checked against the oracle and the golden vectors.  This validates
+kernel logic (layouts, indexing, codecs, sponge padding, rejection sampling, kernel sequencing) before any
+GPU time is spent; the GPU tier (-m gpu) then checks the same things on the real gfx950 build."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import __graft_entry__ as ge
+from conftest import seeds, unhex
+from oracle.loader import SIZES
+
+u8p, u16p = C.POINTER(C.c_uint8), C.POINTER(C.c_uint16)
+
+
+def p8(a):
+    return a.ctypes.data_as(u8p)
+
+
+def p16(a):
+    return a.ctypes.data_as(u16p)
+
+
+@pytest.fixture(scope="module")
+def emu():
+    return C.CDLL(ge.build_emulator())
+
+
+def test_emu_ntt_intt_multiply(emu, oracle, golden_npz):
+    a, b = golden_npz["rand_a"][:6].copy(), golden_npz["rand_b"][:6].copy()
+    out = np.zeros_like(a)
+    emu.emu_ntt(0, C.c_size_t(6), p16(a), p16(out))
+    assert (out == golden_npz["rand_a_ntt"][:6]).all()
+    emu.emu_ntt(1, C.c_size_t(6), p16(a), p16(out))
+    assert (out == golden_npz["rand_a_intt"][:6]).all()
+    emu.emu_basemul(C.c_size_t(6), p16(a), p16(b), p16(out))
+    assert (out == golden_npz["rand_ab_mul"][:6]).all()
+    na, nb = golden_npz["nc_a"][:4].copy(), golden_npz["nc_b"][:4].copy()   # non-canonical 12-bit inputs (F3 path)
+    out = np.zeros_like(na)
+    emu.emu_basemul(C.c_size_t(4), p16(na), p16(nb), p16(out))
+    assert (out == golden_npz["nc_ab_mul"][:4]).all()
+
+
+def test_emu_sampling(emu, oracle, golden_npz):
+    s = golden_npz["g2_in"].copy()
+    out = np.zeros((s.shape[0], 256), np.uint16)
+    emu.emu_sample_ntt(C.c_size_t(s.shape[0]), p8(s), p16(out))
+    assert (out == golden_npz["g2_out"]).all()
+    for eta in (2, 3):
+        b = golden_npz[f"g3_eta{eta}_in"].copy()
+        out = np.zeros((b.shape[0], 256), np.uint16)
+        assert emu.emu_cbd(eta, C.c_size_t(b.shape[0]), p8(b), p16(out)) == 0
+        assert (out == golden_npz[f"g3_eta{eta}_out"]).all()
+        rng = np.random.default_rng(eta)
+        x = rng.integers(0, 256, (65, 33)).astype(np.uint8)
+        o = np.zeros((65, 64 * eta), np.uint8)
+        assert emu.emu_prf(eta, C.c_size_t(65), p8(x), p8(o)) == 0
+        assert all((o[i] == oracle.prf(x[i, :32], int(x[i, 32]), eta)).all() for i in range(65))
+
+
+def test_emu_hashes_all_block_boundaries(emu, oracle):
+    rng = np.random.default_rng(3)
+    for kind, fn, ol in ((0, oracle.H, 32), (1, oracle.G, 64), (2, oracle.J, 32)):
+        for ln in (0, 1, 3, 4, 33, 64, 71, 72, 73, 135, 136, 137, 167, 168, 169, 800, 1120, 1184):
+            n = 65
+            stride = (ln + 3) // 4 * 4 + 4
+            msg = rng.integers(0, 256, (n, stride)).astype(np.uint8)
+            out = np.zeros((n, ol), np.uint8)
+            assert emu.emu_hash(kind, C.c_size_t(n), p8(msg), ln, C.c_size_t(stride), p8(out)) == 0
+            for i in (0, 1, 63, 64):
+                assert (out[i] == fn(msg[i, :ln])).all(), (kind, ln, i)
+
+
+@pytest.mark.parametrize("pset", (512, 768, 1024))
+def test_emu_kem_matches_oracle_and_golden(emu, oracle, golden, pset):
+    ekl, dkl, cl = SIZES[pset]
+    n = 5
+    d, z, m = seeds("emu-d", n, pset), seeds("emu-z", n, pset), seeds("emu-m", n, pset)
+    g = golden["G6_kem"][str(pset)]["recipe"]
+    d[0], z[0], m[0] = unhex(g["d"]), unhex(g["z"]), unhex(g["m"])
+    ek, dk = np.zeros((n, ekl), np.uint8), np.zeros((n, dkl), np.uint8)
+    assert emu.emu_keygen(pset, C.c_size_t(n), p8(d), p8(z), p8(ek), p8(dk)) == 0
+    ek_o, dk_o = oracle.keygen(pset, d, z)
+    assert (ek == ek_o).all() and (dk == dk_o).all()
+    assert bytes(ek[0]).hex() == g["ek"] and bytes(dk[0]).hex() == g["dk"]
+    c, K = np.zeros((n, cl), np.uint8), np.zeros((n, 32), np.uint8)
+    assert emu.emu_encaps(pset, C.c_size_t(n), p8(ek), p8(m), p8(c), p8(K)) == 0
+    c_o, K_o = oracle.encaps(pset, ek, m)
+    assert (c == c_o).all() and (K == K_o).all()
+    assert bytes(c[0]).hex() == g["c"] and bytes(K[0]).hex() == g["K"]
+    cb = c.copy()
+    cb[0, 5] ^= 1            # golden implicit-rejection case
+    cb[3, cl - 1] ^= 0x80    # tamper inside c2
+    dkb = dk.copy()
+    dkb[2, dkl - 64] ^= 1    # stored H(ek) corrupted -> status -5
+    Kd, st = np.zeros((n, 32), np.uint8), np.zeros(n, np.int32)
+    assert emu.emu_decaps(pset, C.c_size_t(n), p8(dkb), p8(cb), p8(Kd), st.ctypes.data_as(C.POINTER(C.c_int32)), 1) == 0
+    Ko, sto = oracle.decaps(pset, dkb, cb)
+    assert (st == sto).all() and st.tolist() == [0, 0, -5, 0, 0]
+    assert (Kd[sto == 0] == Ko[sto == 0]).all()
+    assert bytes(Kd[0]).hex() == g["K_reject_c5_xor1"]
+    assert (Kd[1] == K[1]).all() and (Kd[4] == K[4]).all() and not (Kd[3] == K[3]).all()
