@@ -1,0 +1,304 @@
+#!/usr/bin/env python3
+"""bench.py — BASELINE.json's headline metric on MI355X:
+ML-KEM-768 encaps+decaps pairs per second at batch 2^20 (BASELINE configs[2]), inputs resident in HBM.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload kem768|ntt|kem1024]
+
+One "step" = one pass of the hot path over one batch: Encaps_internal over 2^20 (ek, m) followed by KEM_Decaps
+(hash check included, as the reference's public API does) over the 2^20 (dk, c) it produced.  Keys come from the
+engine's own batch KeyGen on seeds d_i, z_i, m_i = SHAKE128(label || LE64(i) || LE64(0xC0FFEE))[:32] (untimed).
+N > 1: one process per GPU (torchrun), every rank runs the same per-GPU batch on its own item range (weak
+scaling, no collective in the data path); the timed region is bracketed by barrier + synchronize and the MAX
+over ranks is used.  Rank 0 prints ONE JSON line.
+
+Extra objects on the line:
+  roofline      whole-pass algorithmic bytes (5856 B per pair) / pass time vs the 8 TB/s HBM peak, the
+                dominant kernel by HIP-event time, and the integer-VALU view that actually binds this path
+  cpu_baseline  the real reference (oracle/_ref, `kind: reference`) or the oracle restatement (`kind: port`) timed
+                on this box's host cores on a bounded sample of the same items, outputs cross-checked against the GPU
+"""
+import argparse
+import hashlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import __graft_entry__ as ge  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+VALU_PEAK_LANE_OPS = 256 * 4 * 32 * 2.4e9   # 256 CU x 4 SIMD-32 x 2.4 GHz (one 32-bit integer op per lane-clock)
+BENCH_SEED = 0xC0FFEE
+ALGO_BYTES = {"kem768": 5856, "kem1024": 12768, "ntt": 2048}   # SURVEY 8d / BASELINE.md section 4
+# 32-bit VALU lane-operations per unit, from the ISA of this build
+KECCAK_PERM_LANE_OPS = 24 * 180
+
+
+def expand(label, i):
+    return hashlib.shake_128(label.encode() + int(i).to_bytes(8, "little") + BENCH_SEED.to_bytes(8, "little")).digest(32)
+
+
+def device_seeds(label, start, n, device):
+    """Per-item 32-byte seeds.  Item i of the global batch always gets the same seed regardless of sharding: the
+    first 4096 items of a rank use the documented SHAKE128 expander exactly; the bulk is filled by a counter-mode
+    torch generator keyed by (label, start) — synthetic data, generated on the device."""
+    g = torch.Generator(device=device).manual_seed((int.from_bytes(hashlib.sha256(label.encode()).digest()[:6], "little") + start) & (2**62 - 1))
+    out = torch.randint(0, 256, (n, 32), generator=g, device=device, dtype=torch.uint8)
+    head = min(n, 4096)
+    exact = np.frombuffer(b"".join(expand(label, start + i) for i in range(head)), np.uint8).reshape(head, 32)
+    out[:head] = torch.from_numpy(exact.copy()).to(device)
+    return out
+
+
+def dist_setup(n_gpus):
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+    elif n_gpus > 1:
+        raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one process per GPU)")
+    return rank, world, local
+
+
+def barrier(world):
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+
+
+def max_over_ranks(x, world, device):
+    if world == 1:
+        return x
+    import torch.distributed as dist
+    t = torch.tensor([x], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def cpu_baseline(pset, ek, dk, m, c_gpu, K_gpu, want_seconds=20.0):
+    """Time the reference (or the port) on the host cores over a bounded sample of the SAME items."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import loader
+    cores = max(1, min(len(os.sched_getaffinity(0)), 16))
+    n_all = m.shape[0]
+    use_ref = loader.Ref.available()
+    # ~76 ms per pair per core for the reference at -O2; ~0.5 ms for the port
+    per_core = max(2, int(round(want_seconds / 0.080 / cores))) if use_ref else 2000
+    per_core = max(1, min(per_core, n_all // cores))
+    take = per_core * cores
+    ekh, dkh, mh = ek[:take].cpu().numpy(), dk[:take].cpu().numpy(), m[:take].cpu().numpy()
+    if use_ref:
+        ref = loader.Ref()
+        kind = "reference"
+
+        def work(t):
+            sl = slice(t * per_core, (t + 1) * per_core)
+            return ref.time_encaps_decaps(pset, ekh[sl], dkh[sl], mh[sl])
+        label = "reference ml_kem.c+sha3.c (gcc -O2) Encaps_internal + KEM_Decaps"
+    else:
+        orc = loader.Oracle()
+        kind = "port"
+
+        def work(t):
+            sl = slice(t * per_core, (t + 1) * per_core)
+            t0 = time.perf_counter()
+            c, K = orc.encaps(pset, ekh[sl], mh[sl])
+            K2, st = orc.decaps(pset, dkh[sl], c)
+            return time.perf_counter() - t0, c, K, int(((K2 == K).all(axis=1) & (st == 0)).sum())
+        label = "oracle/mlkem_oracle.c restatement (gcc -O2) encaps + decaps"
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(cores) as ex:
+        res = list(ex.map(work, range(cores)))
+    wall = time.perf_counter() - t0
+    pairs = per_core * cores
+    cg, Kg = c_gpu[:pairs].cpu().numpy(), K_gpu[:pairs].cpu().numpy()
+    c_cpu = np.concatenate([r[1] for r in res])
+    K_cpu = np.concatenate([r[2] for r in res])
+    agree = sum(r[3] for r in res)
+    matches_gpu = bool((c_cpu == cg).all() and (K_cpu == Kg).all() and agree == pairs)
+    return {"value": pairs / wall, "unit": "pairs/s", "cores": cores, "kind": kind,
+            "sample": f"{pairs} pairs ({per_core} per thread x {cores} threads) of the benched batch, {label}; "
+                      f"wall {wall:.1f}s; per-core {pairs / sum(r[0] for r in res):.2f} pairs/s",
+            "outputs_match_gpu": matches_gpu}
+
+
+def run_kem(args, pset, rank, world, device):
+    pkg = ge.load_package()
+    n = args.batch
+    eng = pkg.MLKEM(pset, device=device.index, chunk_items=args.chunk)
+    start = rank * n
+    d, z, m = (device_seeds(lbl, start, n, device) for lbl in ("mlkem-bench-d", "mlkem-bench-z", "mlkem-bench-m"))
+    ek, dk = eng.keygen(d, z)          # untimed (configs[2]); configs[3] times it too (workload kem1024)
+    c = torch.empty((n, eng.c_len), dtype=torch.uint8, device=device)
+    K = torch.empty((n, 32), dtype=torch.uint8, device=device)
+    K2 = torch.empty((n, 32), dtype=torch.uint8, device=device)
+    st = torch.empty(n, dtype=torch.int32, device=device)
+    timed_keygen = args.workload == "kem1024"
+
+    def step():
+        if timed_keygen:
+            eng.keygen(d, z, ek=ek, dk=dk)
+        eng.encaps(ek, m, c=c, K=K)
+        eng.decaps(dk, c, K=K2, status=st)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize(device)
+    barrier(world)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize(device)
+    barrier(world)
+    elapsed = max_over_ranks(time.perf_counter() - t0, world, device)
+
+    # correctness gate (outside the timed region)
+    ok = bool(torch.equal(K, K2)) and int(st.abs().max()) == 0
+    ct = c.clone()
+    idx = torch.arange(0, n, 1024, device=device)
+    ct[idx, (idx * 13) % eng.c_len] ^= 2
+    Kt, stt = eng.decaps(dk, ct)
+    same = (Kt == K).all(dim=1)
+    ok = ok and not bool(same[idx].any()) and int(same.sum()) == n - idx.numel() and int(stt.abs().max()) == 0
+
+    extra = {}
+    if rank == 0:
+        # per-kernel HIP-event timing of one more pass (not part of `value`)
+        with pkg.kernel_timing() as kt:
+            step()
+            torch.cuda.synchronize(device)
+        rows = {k: {"ms_total": v[0], "launches": v[1], "ms_avg": v[0] / max(v[1], 1)} for k, v in kt.rows.items()}
+        extra["kernels"] = rows
+        extra["chunk_items"] = args.chunk or int(os.environ.get("MLKEM_CHUNK_ITEMS", 1 << 17))
+        if world == 1 and not args.no_cpu:
+            extra["cpu_baseline"] = cpu_baseline(pset, ek, dk, m, c, K)
+    eng.close()
+    return elapsed, ok, extra
+
+
+def run_ntt(args, rank, world, device):
+    pkg = ge.load_package()
+    n = args.batch
+    eng = pkg.MLKEM(768, device=device.index, chunk_items=1024)
+    g = torch.Generator(device=device).manual_seed(BENCH_SEED + rank)
+    f = torch.randint(0, 3329, (n, 256), generator=g, device=device, dtype=torch.int16)
+    fh = torch.empty_like(f)
+    f2 = torch.empty_like(f)
+    lib, ctx = eng.lib, eng._ctx
+
+    def step():
+        s = eng._stream()
+        eng._check(lib.mlkem_ntt_dev(ctx, n, f.data_ptr(), fh.data_ptr(), s))
+        eng._check(lib.mlkem_intt_dev(ctx, n, fh.data_ptr(), f2.data_ptr(), s))
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize(device)
+    barrier(world)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize(device)
+    barrier(world)
+    elapsed = max_over_ranks(time.perf_counter() - t0, world, device)
+    ok = bool(torch.equal(f, f2)) and int(fh.min()) >= 0 and int(fh.max()) < 3329
+    extra = {}
+    if rank == 0:
+        with pkg.kernel_timing() as kt:
+            step()
+            torch.cuda.synchronize(device)
+        extra["kernels"] = {k: {"ms_total": v[0], "launches": v[1], "ms_avg": v[0] / max(v[1], 1)} for k, v in kt.rows.items()}
+        if world == 1 and not args.no_cpu:
+            from oracle import loader
+            orc = loader.Oracle()
+            sample = f[:20000].cpu().numpy().view(np.uint16)
+            t0 = time.perf_counter()
+            h = orc.ntt(sample)
+            back = orc.intt(h)
+            dt = time.perf_counter() - t0
+            extra["cpu_baseline"] = {"value": sample.shape[0] / dt, "unit": "polys/s", "cores": 1, "kind": "port",
+                                     "sample": "20000 polynomials NTT+InverseNTT, oracle/mlkem_oracle.c (gcc -O2), 1 thread",
+                                     "outputs_match_gpu": bool((h == fh[:20000].cpu().numpy().view(np.uint16)).all() and (back == sample).all())}
+    eng.close()
+    return elapsed, ok, extra
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="kem768", choices=("kem768", "kem1024", "ntt"))
+    ap.add_argument("--batch", type=int, default=1 << 20, help="items per GPU per step (BASELINE: 2^20)")
+    ap.add_argument("--chunk", type=int, default=0, help="engine chunk size in items (0 = library default)")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    args = ap.parse_args()
+
+    rank, world, local = dist_setup(args.gpus)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the engine has no CPU fallback")
+    device = torch.device("cuda", local)
+    torch.cuda.set_device(device)
+
+    if args.workload == "ntt":
+        elapsed, ok, extra = run_ntt(args, rank, world, device)
+        metric, unit = "batched forward+inverse NTT polynomials/sec at batch 2^20", "polys/s"
+        wl = "configs[1]: batched forward+inverse NTT only, %d polynomials per GPU" % args.batch
+        dtype = "int16/int32"
+    else:
+        pset = 768 if args.workload == "kem768" else 1024
+        elapsed, ok, extra = run_kem(args, pset, rank, world, device)
+        if args.workload == "kem768":
+            metric, unit = "ML-KEM-768 encaps+decaps/sec at batch 2^20; achieved HBM GB/s vs peak", "pairs/s"
+            wl = "configs[2]: ML-KEM-768 full Encaps+Decaps (KEM_Decaps incl. dk hash check), batch %d per GPU, keys from batch KeyGen (untimed)" % args.batch
+        else:
+            metric, unit = "ML-KEM-1024 keygen+encaps+decaps/sec at batch 2^20", "triples/s"
+            wl = "configs[3]: ML-KEM-1024 KeyGen+Encaps+Decaps, batch %d per GPU" % args.batch
+        dtype = "u32/int32 (64-bit Keccak lanes as 2 x u32, mod-3329 arithmetic in int32, u8/u16 I/O)"
+
+    if rank != 0:
+        return
+    units = args.batch * world * args.steps
+    value = units / elapsed
+    ms_step = 1e3 * elapsed / args.steps
+    algo = ALGO_BYTES[args.workload]
+    achieved = value / world * algo / 1e9          # per-GPU algorithmic GB/s
+    kernels = extra.get("kernels", {})
+    dom = max(kernels.items(), key=lambda kv: kv[1]["ms_total"])[0] if kernels else None
+    roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "scope": "whole pass (all kernels of one step); algorithmic bytes = %d B/unit x %d units per step" % (algo, args.batch),
+                "dominant_kernel": dom,
+                "dominant_kernel_ms_avg": kernels[dom]["ms_avg"] if dom else None,
+                "dominant_kernel_share": kernels[dom]["ms_total"] / sum(k["ms_total"] for k in kernels.values()) if dom else None}
+    if args.workload == "kem768":
+        # the bound that actually binds: 95 Keccak-f per pair x 4320 32-bit VALU lane-ops, + ~0.3 M for NTT/codec
+        keccak_ops = 95 * KECCAK_PERM_LANE_OPS
+        roofline["binding"] = {"bound": "valu-int32", "keccak_lane_ops_per_pair": keccak_ops,
+                               "keccak_lane_ops_per_s": value / world * keccak_ops,
+                               "peak_lane_ops_per_s": VALU_PEAK_LANE_OPS,
+                               "frac_keccak_only": value / world * keccak_ops / VALU_PEAK_LANE_OPS}
+    line = {"metric": metric, "value": value, "unit": unit, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype,
+            "data": "synthetic", "config": {"workload": wl, "batch_per_gpu": args.batch, "parallelism": "shard%d (no collectives)" % world,
+                                            "chunk_items": extra.get("chunk_items")},
+            "correct": ok, "roofline": roofline, "kernels": kernels}
+    if "cpu_baseline" in extra:
+        line["cpu_baseline"] = extra["cpu_baseline"]
+    print(json.dumps(line))
+    if not ok:
+        sys.exit(3)
+
+
+if __name__ == "__main__":
+    main()

@@ -25,7 +25,7 @@ ERR_HASH = -5
 # every symbol include/mlkem_batch.h declares (checked by tests/test_abi.py without a GPU)
 ABI_SYMBOLS = (
     "mlkem_sizes", "mlkem_params", "mlkem_device_count", "mlkem_strerror", "mlkem_last_hip_error",
-    "mlkem_ctx_create", "mlkem_ctx_destroy", "mlkem_ctx_scratch_bytes",
+    "mlkem_ctx_create", "mlkem_ctx_destroy", "mlkem_ctx_scratch_bytes", "mlkem_timing_begin", "mlkem_timing_end",
     "mlkem_keygen_dev", "mlkem_encaps_dev", "mlkem_decaps_dev",
     "mlkem_ntt_dev", "mlkem_intt_dev", "mlkem_multiply_ntts_dev", "mlkem_sample_ntt_dev", "mlkem_sample_cbd_dev",
     "mlkem_prf_dev", "mlkem_hash_dev",
@@ -52,6 +52,10 @@ def load_library():
     if not os.path.exists(LIB_PATH):
         raise FileNotFoundError(f"{LIB_PATH} missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                                 "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+    # torch must load its HIP runtime BEFORE this library is mapped: the process then has exactly one
+    # libamdhip64/ROCr instance, shared by torch (allocator, streams) and the engine (measured: the other
+    # order leaves the second runtime without a visible device).
+    import torch  # noqa: F401
     L = C.CDLL(LIB_PATH)
     vp, sz, i32 = C.c_void_p, C.c_size_t, C.c_int
     L.mlkem_strerror.restype = C.c_char_p
@@ -78,8 +82,32 @@ def load_library():
     L.mlkem_intt.argtypes = [sz, vp, vp]
     L.mlkem_keygen_random.argtypes = [i32, sz, vp, vp]
     L.mlkem_encaps_random.argtypes = [i32, sz, vp, C.c_uint, vp, vp]
+    L.mlkem_timing_end.argtypes = [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int), i32]
     _lib = L
     return L
+
+
+class kernel_timing:
+    """Context manager: per-kernel HIP-event timing of everything launched inside (bench.py roofline leg).
+    After exit, `.rows` = {label: (total_ms, launches)}."""
+
+    def __enter__(self):
+        self.lib = load_library()
+        rc = self.lib.mlkem_timing_begin()
+        if rc:
+            raise MLKEMError(rc, "timing already active")
+        self.rows = {}
+        return self
+
+    def __exit__(self, *exc):
+        labels = C.create_string_buffer(32 * 64)
+        ms = (C.c_double * 64)()
+        cnt = (C.c_int * 64)()
+        n = self.lib.mlkem_timing_end(labels, ms, cnt, 64)
+        for i in range(max(n, 0)):
+            name = labels.raw[32 * i:32 * i + 32].split(b"\0")[0].decode()
+            self.rows[name] = (ms[i], cnt[i])
+        return False
 
 
 def sizes(param_set):

@@ -136,6 +136,42 @@ void mlkem_ctx_destroy(mlkem_ctx* ctx) {
 
 size_t mlkem_ctx_scratch_bytes(const mlkem_ctx* ctx) { return ctx ? ctx->scratch_bytes : 0; }
 
+// ---- per-kernel timing (measurement aid; HIP events on the launch stream) ----------------------------------
+int mlkem_timing_begin(void) {
+    if (launch_recorder()) return MLKEM_ERR_ARG;
+    launch_recorder() = new LaunchRecorder();
+    return MLKEM_OK;
+}
+// Synchronises, then writes up to `max` rows "label\0" (32 bytes each), total milliseconds and launch counts,
+// aggregated per kernel label; returns the number of rows (or a negative error) and uninstalls the recorder.
+int mlkem_timing_end(char* labels, double* total_ms, int* counts, int max) {
+    LaunchRecorder* rec = launch_recorder();
+    if (!rec) return MLKEM_ERR_ARG;
+    launch_recorder() = nullptr;
+    int rows = 0;
+    for (auto& r : rec->recs) {
+        float ms = 0.f;
+        if (hipEventSynchronize(r.b) == hipSuccess) (void)hipEventElapsedTime(&ms, r.a, r.b);
+        (void)hipEventDestroy(r.a);
+        (void)hipEventDestroy(r.b);
+        int k = 0;
+        for (; k < rows; k++)
+            if (strncmp(labels + 32 * k, r.label, 31) == 0) break;
+        if (k == rows) {
+            if (rows >= max) continue;
+            memset(labels + 32 * k, 0, 32);
+            strncpy(labels + 32 * k, r.label, 31);
+            total_ms[k] = 0;
+            counts[k] = 0;
+            rows++;
+        }
+        total_ms[k] += ms;
+        counts[k] += 1;
+    }
+    delete rec;
+    return rows;
+}
+
 // ---- device-pointer KEM ------------------------------------------------------------------------------
 
 int mlkem_keygen_dev(mlkem_ctx* ctx, int set, size_t n, const uint8_t* d, const uint8_t* z, uint8_t* ek, uint8_t* dk, void* stream) {

@@ -61,6 +61,13 @@ int mlkem_ctx_create(mlkem_ctx** out, int device, size_t chunk_items);
 void mlkem_ctx_destroy(mlkem_ctx* ctx);
 size_t mlkem_ctx_scratch_bytes(const mlkem_ctx* ctx);
 
+/* ---- per-kernel timing (measurement aid used by bench.py) ---------------------------------------------
+ * Between begin and end, every kernel launched by this thread is bracketed by HIP events on its launch
+ * stream.  mlkem_timing_end synchronises and returns per-kernel-label rows: labels[32*i..] (NUL-terminated),
+ * total_ms[i], counts[i]; return value = number of rows (<= max) or a negative error. */
+int mlkem_timing_begin(void);
+int mlkem_timing_end(char* labels, double* total_ms, int* counts, int max);
+
 /* ---- batched KEM, device pointers ----------------------------------------------------------------- */
 /* replaces KeyGen_internal(params, d, z)          ml_kem.c:1034-1084   (d, z : n x 32 ; ek : n x ek_len ; dk : n x dk_len) */
 int mlkem_keygen_dev(mlkem_ctx* ctx, int param_set, size_t n, const uint8_t* d, const uint8_t* z, uint8_t* ek, uint8_t* dk,
