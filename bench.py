@@ -92,8 +92,11 @@ def cpu_baseline(pset, ek, dk, m, c_gpu, K_gpu, want_seconds=20.0):
     cores = max(1, min(len(os.sched_getaffinity(0)), 16))
     n_all = m.shape[0]
     use_ref = loader.Ref.available()
-    # ~76 ms per pair per core for the reference at -O2; ~0.5 ms for the port
-    per_core = max(2, int(round(want_seconds / 0.080 / cores))) if use_ref else 2000
+    if use_ref:   # calibrate on one pair (30-80 ms per pair per core at -O2), then size for ~want_seconds of CPU work
+        t1 = loader.Ref().time_encaps_decaps(pset, ek[:1].cpu().numpy(), dk[:1].cpu().numpy(), m[:1].cpu().numpy())[0]
+        per_core = max(2, min(512, int(round(want_seconds / max(t1, 1e-3) / cores))))
+    else:
+        per_core = 2000   # the port runs ~0.5 ms per pair
     per_core = max(1, min(per_core, n_all // cores))
     take = per_core * cores
     ekh, dkh, mh = ek[:take].cpu().numpy(), dk[:take].cpu().numpy(), m[:take].cpu().numpy()
