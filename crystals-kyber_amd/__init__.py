@@ -277,7 +277,7 @@ class MLKEM:
             msgs = torch.as_tensor(msgs)
         msgs = msgs.to(device=self.device, dtype=torch.uint8)
         n, ln = msgs.shape
-        stride = (ln + 3) // 4 * 4 + 4
+        stride = (ln + 7) // 8 * 8 + 8
         padded = torch.zeros((n, stride), dtype=torch.uint8, device=self.device)
         padded[:, :ln] = msgs
         out = self._out(n, outlen)

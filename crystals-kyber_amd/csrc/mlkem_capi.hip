@@ -106,10 +106,18 @@ int mlkem_ctx_create(mlkem_ctx** out, int device, size_t chunk_items) {
     c->device = device;
     c->chunk = chunk_items ? chunk_items : default_chunk();
     const size_t n = c->chunk;
-    // carve one allocation: A | prf | r | rho | m | Kp | Kbar, each 256-byte aligned
+    // hash stages run over h-chunks of 8 chunks (>= 2^16 items keeps 1024 SIMDs busy with one sponge per lane)
+    size_t hn = n * 8;
+    if (const char* e = getenv("MLKEM_HCHUNK_ITEMS")) {
+        long long v = atoll(e);
+        if (v > 0) hn = (size_t)v;
+    }
+    if (hn < n) hn = n;
+    if (const char* e = getenv("MLKEM_RING")) c->ws.ring = atoi(e) == 128 ? 128 : 64;
+    // carve one allocation: A | prf | leftover | r | rho | m | Kp | Kbar, each 256-byte aligned
     auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
-    const size_t szA = up(n * 16 * 512), szP = up(n * 9 * 192), sz32 = up(n * 32);
-    c->scratch_bytes = szA + szP + 5 * sz32;
+    const size_t szA = up(n * 16 * 512), szP = up(n * 9 * 192), szL = up((n * 16 + 1) * 4), sz32 = up(hn * 32);
+    c->scratch_bytes = szA + szP + szL + 5 * sz32;
     if (!hip_ok(hipMalloc(&c->scratch, c->scratch_bytes), "hipMalloc(scratch)")) {
         delete c;
         return MLKEM_ERR_ALLOC;
@@ -117,12 +125,14 @@ int mlkem_ctx_create(mlkem_ctx** out, int device, size_t chunk_items) {
     uint8_t* base = static_cast<uint8_t*>(c->scratch);
     c->ws.A = reinterpret_cast<uint16_t*>(base);
     c->ws.prf = base + szA;
-    c->ws.r = c->ws.prf + szP;
+    c->ws.leftover = reinterpret_cast<uint32_t*>(c->ws.prf + szP);
+    c->ws.r = c->ws.prf + szP + szL;
     c->ws.rho = c->ws.r + sz32;
     c->ws.m = c->ws.rho + sz32;
     c->ws.Kp = c->ws.m + sz32;
     c->ws.Kbar = c->ws.Kp + sz32;
-    c->ws.cap_items = n;
+    c->ws.cap = n;
+    c->ws.hcap = hn;
     *out = c;
     return MLKEM_OK;
 }
@@ -180,10 +190,7 @@ int mlkem_keygen_dev(mlkem_ctx* ctx, int set, size_t n, const uint8_t* d, const 
     if (!ctx || (n && (!d || !z || !ek || !dk))) return MLKEM_ERR_ARG;
     if (!aligned16(d) || !aligned16(z) || !aligned16(ek) || !aligned16(dk)) return MLKEM_ERR_ARG;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    for (size_t off = 0; off < n; off += ctx->chunk) {
-        const size_t m = n - off < ctx->chunk ? n - off : ctx->chunk;
-        keygen_dispatch(st, set, m, d + off * 32, z + off * 32, ek + off * p.ek_len, dk + off * p.dk_len, ctx->ws);
-    }
+    keygen_dispatch(st, set, n, d, z, ek, dk, ctx->ws);   // chunks internally through ctx->ws
     HIP_TRY(hipGetLastError());
     return MLKEM_OK;
 }
@@ -194,10 +201,7 @@ int mlkem_encaps_dev(mlkem_ctx* ctx, int set, size_t n, const uint8_t* ek, const
     if (!ctx || (n && (!ek || !m || !c || !K))) return MLKEM_ERR_ARG;
     if (!aligned16(ek) || !aligned16(m) || !aligned16(c) || !aligned16(K)) return MLKEM_ERR_ARG;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    for (size_t off = 0; off < n; off += ctx->chunk) {
-        const size_t cnt = n - off < ctx->chunk ? n - off : ctx->chunk;
-        encaps_dispatch(st, set, cnt, ek + off * p.ek_len, m + off * 32, c + off * p.c_len, K + off * 32, ctx->ws);
-    }
+    encaps_dispatch(st, set, n, ek, m, c, K, ctx->ws);
     HIP_TRY(hipGetLastError());
     return MLKEM_OK;
 }
@@ -208,11 +212,7 @@ int mlkem_decaps_dev(mlkem_ctx* ctx, int set, size_t n, const uint8_t* dk, const
     if (!ctx || (n && (!dk || !c || !K))) return MLKEM_ERR_ARG;
     if (!aligned16(dk) || !aligned16(c) || !aligned16(K) || (reinterpret_cast<uintptr_t>(status) & 3u)) return MLKEM_ERR_ARG;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    for (size_t off = 0; off < n; off += ctx->chunk) {
-        const size_t cnt = n - off < ctx->chunk ? n - off : ctx->chunk;
-        decaps_dispatch(st, set, cnt, dk + off * p.dk_len, c + off * p.c_len, K + off * 32, status ? status + off : nullptr,
-                        status != nullptr, ctx->ws);
-    }
+    decaps_dispatch(st, set, n, dk, c, K, status, status != nullptr, ctx->ws);
     HIP_TRY(hipGetLastError());
     return MLKEM_OK;
 }

@@ -20,57 +20,68 @@ namespace mlkem {
 constexpr int WAVE = 64;
 
 // ================================================================================================
-// LDS-staged absorption: 64 lanes each own one sponge; the wave cooperatively reads, for every item,
-// the next `nbytes` of a virtual message made of two segments (seg0 then seg1), each with its own
-// base / per-item stride, and every lane then XORs its row into its state.
-// Row stride in the stage is RATE/4 + 1 dwords (odd) so the per-lane row reads are bank-conflict free.
+// LDS-staged absorption: 64 lanes each own one sponge.  For every rate block the wave reads the 64 rows
+// (one per item) x RATE bytes of a virtual message made of two segments (seg0 then seg1, each with its own
+// base / per-item stride) as RATE/8 fully coalesced 8-byte-per-lane loads (flat index f = it*64 + lane ->
+// row f / NQ, qword f % NQ), stores them linearly into LDS, and every lane then XORs its own row into its
+// state.  NQ = RATE/8 is odd for all three rates (17, 21, 9), so the per-lane ds_read_b64 row reads are
+// bank-conflict free without padding.  Bytes past the end of the message are staged as zeros.
+// Requirements: bases and strides 8-byte aligned; len0 % 8 == 0 whenever len1 != 0.
 // ================================================================================================
 struct MsgView {
     const uint8_t* p0; size_t stride0; unsigned len0;   // segment 0 (may have len0 = 0)
     const uint8_t* p1; size_t stride1; unsigned len1;   // segment 1
 };
 
-__device__ __forceinline__ uint32_t load_word_tail(const uint8_t* p, unsigned avail) {
-    // p is 4-byte aligned; `avail` (1..) bytes are readable
-    if (avail >= 4) return *reinterpret_cast<const uint32_t*>(p);
-    uint32_t v = p[0];
-    if (avail > 1) v |= (uint32_t)p[1] << 8;
-    if (avail > 2) v |= (uint32_t)p[2] << 16;
+__device__ __forceinline__ uint2 load_qword_tail(const uint8_t* p, unsigned avail) {
+    // p is 8-byte aligned; `avail` (>= 1) bytes are readable
+    if (avail >= 8) return *reinterpret_cast<const uint2*>(p);
+    uint2 v;
+    v.x = 0; v.y = 0;
+    for (unsigned i = 0; i < avail; i++) {
+        const uint32_t b = p[i];
+        if (i < 4) v.x |= b << (8 * i);
+        else v.y |= b << (8 * (i - 4));
+    }
     return v;
 }
 
 template <int RATE>
-__device__ __forceinline__ void wave_stage_block(uint32_t* stage, const MsgView& mv, size_t item0, size_t n_items,
-                                                 unsigned voff, unsigned nbytes) {
-    constexpr int RS = RATE / 4 + 1;
-    const int l = lane_id();
-    const unsigned nwords = (nbytes + 3) / 4;
-    const unsigned pos = voff + 4u * (unsigned)l;   // virtual byte offset of this lane's dword
-    if ((unsigned)l < nwords) {
-        for (int row = 0; row < WAVE; row++) {
-            size_t item = item0 + (size_t)row;
-            if (item >= n_items) item = n_items - 1;   // clamp: rows beyond the batch are computed but never stored
-            uint32_t v;
-            if (pos < mv.len0) v = load_word_tail(mv.p0 + item * mv.stride0 + pos, mv.len0 - pos);
-            else v = load_word_tail(mv.p1 + item * mv.stride1 + (pos - mv.len0), mv.len0 + mv.len1 - pos);
-            stage[row * RS + l] = v;
+__device__ __forceinline__ void wave_stage_block(uint2* stage, const MsgView& mv, size_t item0, size_t n_items, unsigned voff) {
+    constexpr int NQ = RATE / 8;
+    const unsigned l = (unsigned)lane_id(), total = mv.len0 + mv.len1;
+    // loads are issued in groups of 7 (7 x 8 B per lane in flight): enough memory-level parallelism without
+    // pushing the kernel past 128 VGPRs next to the 50-register Keccak state
+#pragma unroll 1
+    for (int it0 = 0; it0 < NQ; it0 += 7)
+#pragma unroll
+    for (int it = it0; it < it0 + 7; it++) {
+        if (it >= NQ) break;
+        const unsigned f = (unsigned)it * WAVE + l, row = f / NQ, col = f - row * NQ;
+        size_t item = item0 + row;
+        if (item >= n_items) item = n_items - 1;   // rows beyond the batch are computed but never stored
+        const unsigned pos = voff + 8u * col;
+        uint2 v;
+        v.x = 0; v.y = 0;
+        if (pos < total) {
+            if (pos < mv.len0) v = load_qword_tail(mv.p0 + item * mv.stride0 + pos, mv.len0 - pos);
+            else v = load_qword_tail(mv.p1 + item * mv.stride1 + (pos - mv.len0), total - pos);
         }
+        stage[f] = v;
     }
 }
 
-// XOR the first `nwords` dwords of this lane's staged row into its state
+// XOR this lane's staged row (RATE bytes) into its state
 template <int RATE>
-__device__ __forceinline__ void lane_xor_row(KeccakState& s, const uint32_t* stage, unsigned nwords) {
-    constexpr int RS = RATE / 4 + 1;
-    const uint32_t* row = stage + lane_id() * RS;
-#define MLKEM_XW(W) if constexpr (W < RATE / 4) { if ((unsigned)W < nwords) keccak_word<W>(s) ^= row[W]; }
-    MLKEM_XW(0) MLKEM_XW(1) MLKEM_XW(2) MLKEM_XW(3) MLKEM_XW(4) MLKEM_XW(5) MLKEM_XW(6) MLKEM_XW(7)
-    MLKEM_XW(8) MLKEM_XW(9) MLKEM_XW(10) MLKEM_XW(11) MLKEM_XW(12) MLKEM_XW(13) MLKEM_XW(14) MLKEM_XW(15)
-    MLKEM_XW(16) MLKEM_XW(17) MLKEM_XW(18) MLKEM_XW(19) MLKEM_XW(20) MLKEM_XW(21) MLKEM_XW(22) MLKEM_XW(23)
-    MLKEM_XW(24) MLKEM_XW(25) MLKEM_XW(26) MLKEM_XW(27) MLKEM_XW(28) MLKEM_XW(29) MLKEM_XW(30) MLKEM_XW(31)
-    MLKEM_XW(32) MLKEM_XW(33) MLKEM_XW(34) MLKEM_XW(35) MLKEM_XW(36) MLKEM_XW(37) MLKEM_XW(38) MLKEM_XW(39)
-    MLKEM_XW(40) MLKEM_XW(41)
-#undef MLKEM_XW
+__device__ __forceinline__ void lane_xor_row(KeccakState& s, const uint2* stage) {
+    constexpr int NQ = RATE / 8;
+    const uint2* row = stage + lane_id() * NQ;
+#pragma unroll
+    for (int w = 0; w < NQ; w++) {
+        const uint2 v = row[w];
+        s.lo[w] ^= v.x;
+        s.hi[w] ^= v.y;
+    }
 }
 
 // xor `byte` at runtime byte position `pos` (wave-uniform) — used for the domain/pad byte of a
@@ -91,24 +102,24 @@ __device__ __forceinline__ void keccak_xor_byte_rt(KeccakState& s, unsigned pos,
 // Full sponge absorb of a (two-segment) message of wave-uniform length; leaves the state after the
 // final permutation (ready to squeeze).  sha3.c:257-291 + :408-436; SUFFIX = 0x06 (SHA-3) / 0x1F (SHAKE).
 template <int RATE, int SUFFIX>
-__device__ __forceinline__ void wave_sponge_absorb(KeccakState& s, uint32_t* stage, const MsgView& mv, size_t item0,
+__device__ __forceinline__ void wave_sponge_absorb(KeccakState& s, uint2* stage, const MsgView& mv, size_t item0,
                                                    size_t n_items) {
     const unsigned total = mv.len0 + mv.len1;
     keccak_zero(s);
     unsigned voff = 0;
     while (total - voff >= (unsigned)RATE) {
-        wave_stage_block<RATE>(stage, mv, item0, n_items, voff, RATE);
+        wave_stage_block<RATE>(stage, mv, item0, n_items, voff);
         wave_lds_fence();
-        lane_xor_row<RATE>(s, stage, RATE / 4);
+        lane_xor_row<RATE>(s, stage);
         wave_lds_fence();
         keccak_f1600(s);
         voff += RATE;
     }
     const unsigned rem = total - voff;
     if (rem) {
-        wave_stage_block<RATE>(stage, mv, item0, n_items, voff, rem);
+        wave_stage_block<RATE>(stage, mv, item0, n_items, voff);
         wave_lds_fence();
-        lane_xor_row<RATE>(s, stage, (rem + 3) / 4);
+        lane_xor_row<RATE>(s, stage);
         wave_lds_fence();
     }
     keccak_xor_byte_rt(s, rem, SUFFIX);
@@ -116,7 +127,7 @@ __device__ __forceinline__ void wave_sponge_absorb(KeccakState& s, uint32_t* sta
     keccak_f1600(s);
 }
 
-constexpr int STAGE_WORDS = WAVE * (168 / 4 + 1);   // largest rate (SHAKE128)
+constexpr int STAGE_QWORDS = WAVE * (168 / 8);   // largest rate (SHAKE128): 10752 bytes per wave
 
 // store / load 8 dwords (32 bytes) of per-item data: row `item` of a [n][32]-byte array
 __device__ __forceinline__ void store32(uint8_t* base, size_t stride, size_t item, const uint32_t (&w)[8]) {
@@ -158,7 +169,7 @@ __device__ __forceinline__ void lane_G64(KeccakState& s, const uint32_t (&x)[8],
 template <int K>
 __global__ void __launch_bounds__(WAVE) k_hash_encaps(size_t n, const uint8_t* __restrict__ ek, const uint8_t* __restrict__ m,
                                                       uint8_t* __restrict__ Kout, uint8_t* __restrict__ r_ws) {
-    __shared__ uint32_t stage[STAGE_WORDS];
+    __shared__ __attribute__((aligned(16))) uint2 stage[STAGE_QWORDS];
     constexpr unsigned EK = 384 * K + 32;
     const size_t item0 = (size_t)blockIdx.x * WAVE, item = item0 + lane_id();
     KeccakState s;
@@ -187,7 +198,7 @@ __global__ void __launch_bounds__(WAVE) k_hash_decaps(size_t n, const uint8_t* _
                                                       const uint8_t* __restrict__ m_ws, uint8_t* __restrict__ Kp_ws,
                                                       uint8_t* __restrict__ r_ws, uint8_t* __restrict__ Kbar_ws,
                                                       int32_t* __restrict__ status) {
-    __shared__ uint32_t stage[STAGE_WORDS];
+    __shared__ __attribute__((aligned(16))) uint2 stage[STAGE_QWORDS];
     constexpr unsigned EK = 384 * K + 32, DK = 768 * K + 96;
     const size_t item0 = (size_t)blockIdx.x * WAVE, item = item0 + lane_id();
     const size_t it = item < n ? item : n - 1;
@@ -257,7 +268,7 @@ __global__ void __launch_bounds__(WAVE) k_hash_keygen_seed(size_t n, const uint8
 template <int K>
 __global__ void __launch_bounds__(WAVE) k_hash_keygen_fin(size_t n, const uint8_t* __restrict__ ek, const uint8_t* __restrict__ z,
                                                           uint8_t* __restrict__ dk) {
-    __shared__ uint32_t stage[STAGE_WORDS];
+    __shared__ __attribute__((aligned(16))) uint2 stage[STAGE_QWORDS];
     constexpr unsigned EK = 384 * K + 32, DK = 768 * K + 96;
     const size_t item0 = (size_t)blockIdx.x * WAVE, item = item0 + lane_id();
     KeccakState s;
@@ -278,7 +289,7 @@ __global__ void __launch_bounds__(WAVE) k_hash_keygen_fin(size_t n, const uint8_
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(WAVE) k_hash_batch(size_t n, int kind, const uint8_t* __restrict__ msg, unsigned len,
                                                      size_t stride, uint8_t* __restrict__ out) {
-    __shared__ uint32_t stage[STAGE_WORDS];
+    __shared__ __attribute__((aligned(16))) uint2 stage[STAGE_QWORDS];
     const size_t item0 = (size_t)blockIdx.x * WAVE, item = item0 + lane_id();
     KeccakState s;
     MsgView mv{msg, stride, len, msg, stride, 0};
@@ -331,12 +342,17 @@ struct SampleArgs {
     int eta1;
     uint8_t* prf;             // output rows
     unsigned prf_stride;
+    // leftover list shared by k_sample_main (producer) and k_sample in list mode (consumer):
+    // leftover[0] = count, leftover[1..] = sponge indices that need more than three squeeze blocks
+    uint32_t* leftover;
+    int list_mode;            // k_sample only: take the sponge indices from `leftover` (grid-stride)
 };
 
-// flush every lane-ring chunk that has become complete; ring rows live in `ring` (this wave's slice)
-__device__ __forceinline__ void ring_flush(const int16_t* ring, uint16_t* A, size_t g, size_t n_xof, int cnt, int& flushed) {
+// flush every lane-ring chunk that has become complete; ring rows live in `ring` (this wave's slice).
+// `g` is this lane's sponge index (lanes need not hold consecutive sponges), `valid` = lane owns a real sponge.
+__device__ __forceinline__ void ring_flush(const int16_t* ring, uint16_t* A, size_t g, bool valid, int cnt, int& flushed) {
     const int l = lane_id();
-    const int has = (cnt - flushed >= 64) && (g < n_xof);
+    const int has = (cnt - flushed >= 64) && valid;
     if (__ballot(has) == 0) return;
     const int grp = l >> 3, sub = l & 7;
 #pragma unroll 1
@@ -344,10 +360,10 @@ __device__ __forceinline__ void ring_flush(const int16_t* ring, uint16_t* A, siz
         const int p = step * 8 + grp;                       // lane (= polynomial of this wave) being flushed
         const int p_has = __shfl(has, p);
         const int p_flushed = __shfl(flushed, p);
+        const size_t gp = (size_t)(uint32_t)__shfl((int)(uint32_t)g, p);   // sponge index of lane p (< 2^32)
         if (p_has) {
             const int16_t* src = ring + p * RING_STRIDE + (p_flushed & (RING - 1)) + sub * 8;
             uint4 v = *reinterpret_cast<const uint4*>(src);
-            const size_t gp = g - (size_t)l + (size_t)p;     // sponge index of lane p
             *reinterpret_cast<uint4*>(A + gp * 256 + p_flushed + sub * 8) = v;
         }
     }
@@ -378,9 +394,17 @@ __global__ void __launch_bounds__(WAVE) k_sample(SampleArgs a) {
     const int l = lane_id();
     KeccakState s;
     if (blockIdx.x < a.xof_blocks) {
-        // ---------------- XOF role: SampleNTT ----------------
-        const size_t g = (size_t)blockIdx.x * WAVE + l;
-        const size_t gc = g < a.n_xof ? g : a.n_xof - 1;
+        // ---------------- XOF role: SampleNTT (general form: up to 5 blocks + the reference's retry) ----------------
+        // direct mode: one pass, sponge = block*64 + lane.  list mode: sponges come from the leftover list written by
+        // k_sample_main; the grid strides over the list (its length is only known on the device).
+        const size_t limit = a.list_mode ? (size_t)a.leftover[0] : a.n_xof;
+        const size_t stride = a.list_mode ? (size_t)gridDim.x * WAVE : ~(size_t)0 / 2;
+      for (size_t base = (size_t)blockIdx.x * WAVE; base < limit; base += stride) {
+        const size_t slot = base + l;
+        const bool valid = slot < limit;
+        const size_t slot_c = valid ? slot : limit - 1;
+        const size_t g = a.list_mode ? (size_t)a.leftover[1 + slot_c] : slot_c;
+        const size_t gc = g;
         uint32_t seed[8];
         unsigned i0, i1;
         if (a.K) {
@@ -417,7 +441,7 @@ __global__ void __launch_bounds__(WAVE) k_sample(SampleArgs a) {
             MLKEM_GROUP4(0, 4) MLKEM_GROUP4(3, 4) MLKEM_GROUP4(6, 4) MLKEM_GROUP4(9, 4)
             MLKEM_GROUP4(12, 4) MLKEM_GROUP4(15, 4) MLKEM_GROUP4(18, 4)
             wave_lds_fence();
-            ring_flush(ring, a.A, g, a.n_xof, cnt, flushed);
+            ring_flush(ring, a.A, g, valid, cnt, flushed);
             wave_lds_fence();
             // second half: triples 28..55 (dwords 21..41); in the 5th block the reference never uses
             // triples 278, 279 (ml_kem.c:223-227: the 279th triple only trips the iteration limit)
@@ -425,7 +449,7 @@ __global__ void __launch_bounds__(WAVE) k_sample(SampleArgs a) {
             MLKEM_GROUP4(33, 4) MLKEM_GROUP4(36, 4)
             if (blk == 4) MLKEM_GROUP4(39, 2) else MLKEM_GROUP4(39, 4)
             wave_lds_fence();
-            ring_flush(ring, a.A, g, a.n_xof, cnt, flushed);
+            ring_flush(ring, a.A, g, valid, cnt, flushed);
             wave_lds_fence();
             blk++;
             if (blk == 5 && cnt < 256) {   // ml_kem.c:237-242: B[32]++, B[33]++ and start over
@@ -435,6 +459,8 @@ __global__ void __launch_bounds__(WAVE) k_sample(SampleArgs a) {
             }
             if (__ballot(cnt < 256) == 0) break;
         }
+        wave_lds_fence();
+      }
     } else {
         // ---------------- PRF role ----------------
         const size_t g = (size_t)(blockIdx.x - a.xof_blocks) * WAVE + l;

@@ -4,8 +4,15 @@
 // and by g++ into the test-only wave emulator (tests/emu), which runs the identical kernel bodies on
 // 64 host threads per wave so that kernel logic can be checked without a GPU.  There is no CPU fallback
 // in the product: the emulator is never built into, or loaded by, libmlkem_amd.so.
+//
+// Two granularities:
+//   hash stages (lane = item, 32-byte results)   run over "h-chunks" of up to Workspace::hcap items, so that even
+//                                                 a serial 9-permutation sponge per lane fills 1024 SIMDs;
+//   sampler + polynomial arithmetic               run over chunks of Workspace::cap items, because their
+//                                                 intermediates (A-hat, PRF bytes: ~5.5 KB per item) live in scratch.
 #pragma once
 #include "mlkem_kernels.hpp"
+#include "mlkem_sampler.hpp"
 #ifndef MLKEM_EMU
 #include <vector>
 #endif
@@ -53,6 +60,15 @@ inline void launch(const char* label, void (*kfn)(KArgs...), size_t grid, unsign
 #endif
 }
 
+inline void zero_u32(stream_t st, uint32_t* p) {
+#ifdef MLKEM_EMU
+    (void)st;
+    *p = 0;
+#else
+    (void)hipMemsetAsync(p, 0, sizeof(uint32_t), st);
+#endif
+}
+
 struct ParamSet {
     int set, k, eta1, eta2, du, dv;
     unsigned ek_len, dk_len, c_len;
@@ -71,19 +87,25 @@ inline bool param_set(int set, ParamSet& p) {
     return true;
 }
 
-// Per-chunk scratch in HBM (bytes per item for parameter k, worst case over the three operations):
-//   A    k*k*512   sampled matrix, uint16 coefficients, natural order
-//   prf  (2k+1)*PS raw PRF output rows (PS = 192 for eta1 = 3, else 128)
-//   r, rho, m, Kp, Kbar : 32 each
+// Scratch in HBM.  Per chunk item (worst case k = 4):
+//   A        k*k*512   sampled matrix, uint16 coefficients, natural order
+//   prf      (2k+1)*PS raw PRF output rows (PS = 192 for eta1 = 3, else 128)
+//   leftover 4*(k*k)   sponge indices needing a 4th squeeze block (+1 counter word)
+// Per h-chunk item: r, rho, m, Kp, Kbar : 32 bytes each.
 struct Workspace {
     uint16_t* A = nullptr;
     uint8_t *prf = nullptr, *r = nullptr, *rho = nullptr, *m = nullptr, *Kp = nullptr, *Kbar = nullptr;
-    size_t cap_items = 0;   // capacity in items at k = 4
-    static size_t bytes_per_item() { return 16 * 512 + 9 * 192 + 5 * 32; }
+    uint32_t* leftover = nullptr;
+    size_t cap = 0;    // chunk capacity (items) of A / prf / leftover
+    size_t hcap = 0;   // h-chunk capacity (items) of the 32-byte arrays
+    int ring = 64;     // sampler LDS ring size (64 or 128 coefficients per lane)
 };
 
 inline size_t ceil_div(size_t a, size_t b) { return (a + b - 1) / b; }
+inline size_t min_sz(size_t a, size_t b) { return a < b ? a : b; }
 
+// SampleNTT for the k x k matrix + PRF rows of `n` items: the three-block main kernel, then the general kernel over
+// the leftover list (ml_kem.c:189-245, :496-515)
 inline void launch_sample(stream_t st, const ParamSet& p, size_t n, const uint8_t* rho, size_t rho_stride, int transpose,
                           const uint8_t* r, int prf_per_item, int n_eta1, const Workspace& ws) {
     SampleArgs a{};
@@ -93,47 +115,84 @@ inline void launch_sample(stream_t st, const ParamSet& p, size_t n, const uint8_
     a.n_prf = n * (size_t)prf_per_item;
     a.r = r; a.per_item = prf_per_item; a.n_eta1 = n_eta1; a.eta1 = p.eta1; a.prf = ws.prf;
     a.prf_stride = p.eta1 == 3 ? 192 : 128;
-    launch("k_sample", k_sample, a.xof_blocks + ceil_div(a.n_prf, WAVE), WAVE, st, a);
+    a.leftover = ws.leftover;
+    a.list_mode = 0;
+    zero_u32(st, ws.leftover);
+    const size_t grid = a.xof_blocks + ceil_div(a.n_prf, WAVE);
+    if (ws.ring == 128) launch("k_sample_main", k_sample_main<128>, grid, WAVE, st, a);
+    else launch("k_sample_main", k_sample_main<64>, grid, WAVE, st, a);
+    // leftovers: expected 0.8 % of the sponges; the grid covers 1/16 of them and strides over the rest if ever needed
+    SampleArgs t = a;
+    t.list_mode = 1;
+    t.n_prf = 0;
+    t.xof_blocks = (unsigned)(ceil_div(a.n_xof, WAVE * 16) + 1);
+    launch("k_sample_tail", k_sample, (size_t)t.xof_blocks, WAVE, st, t);
 }
 
 // ---- ML-KEM.KeyGen_internal (ml_kem.c:1034-1084) -------------------------------------------------
 template <int K, int ETA1>
-inline void keygen_chunk(stream_t st, const ParamSet& p, size_t n, const uint8_t* d, const uint8_t* z, uint8_t* ek, uint8_t* dk,
-                         const Workspace& ws) {
-    launch("k_hash_keygen_seed", k_hash_keygen_seed<K>, ceil_div(n, WAVE), WAVE, st, n, d, ws.rho, ws.r);
-    launch_sample(st, p, n, ws.rho, 32, /*transpose=*/0, ws.r, 2 * K, 2 * K, ws);
-    launch("k_keygen", k_keygen<K, ETA1>, ceil_div(n, ARITH_WAVES), WAVE * ARITH_WAVES, st, n, (const uint16_t*)ws.A, (const uint8_t*)ws.prf,
-           (const uint8_t*)ws.rho, ek, dk);
-    launch("k_hash_keygen_fin", k_hash_keygen_fin<K>, ceil_div(n, WAVE), WAVE, st, n, (const uint8_t*)ek, z, dk);
+inline void keygen_run(stream_t st, const ParamSet& p, size_t n, const uint8_t* d, const uint8_t* z, uint8_t* ek, uint8_t* dk,
+                       const Workspace& ws) {
+    for (size_t h0 = 0; h0 < n; h0 += ws.hcap) {
+        const size_t hn = min_sz(ws.hcap, n - h0);
+        launch("k_hash_keygen_seed", k_hash_keygen_seed<K>, ceil_div(hn, WAVE), WAVE, st, hn, d + h0 * 32, ws.rho, ws.r);
+        for (size_t c0 = 0; c0 < hn; c0 += ws.cap) {
+            const size_t cn = min_sz(ws.cap, hn - c0), i0 = h0 + c0;
+            launch_sample(st, p, cn, ws.rho + c0 * 32, 32, /*transpose=*/0, ws.r + c0 * 32, 2 * K, 2 * K, ws);
+            launch("k_keygen", k_keygen<K, ETA1>, ceil_div(cn, ARITH_WAVES), WAVE * ARITH_WAVES, st, cn, (const uint16_t*)ws.A,
+                   (const uint8_t*)ws.prf, (const uint8_t*)(ws.rho + c0 * 32), ek + i0 * p.ek_len, dk + i0 * p.dk_len);
+        }
+        launch("k_hash_keygen_fin", k_hash_keygen_fin<K>, ceil_div(hn, WAVE), WAVE, st, hn, (const uint8_t*)(ek + h0 * p.ek_len),
+               z + h0 * 32, dk + h0 * p.dk_len);
+    }
 }
 
 // ---- ML-KEM.Encaps_internal (ml_kem.c:1093-1130) -------------------------------------------------
 template <int K, int ETA1, int DU, int DV>
-inline void encaps_chunk(stream_t st, const ParamSet& p, size_t n, const uint8_t* ek, const uint8_t* m, uint8_t* c, uint8_t* Kout,
-                         const Workspace& ws) {
-    launch("k_hash_encaps", k_hash_encaps<K>, ceil_div(n, WAVE), WAVE, st, n, ek, m, Kout, ws.r);
-    launch_sample(st, p, n, ek + 384 * K, p.ek_len, /*transpose=*/1, ws.r, 2 * K + 1, K, ws);
-    launch("k_encrypt", k_encrypt<K, ETA1, DU, DV, false>, ceil_div(n, ARITH_WAVES), WAVE * ARITH_WAVES, st, n, ek, (size_t)p.ek_len, m,
-           (const uint16_t*)ws.A, (const uint8_t*)ws.prf, c, (const uint8_t*)nullptr, (const uint8_t*)nullptr,
-           (const uint8_t*)nullptr, (uint8_t*)nullptr);
+inline void encaps_run(stream_t st, const ParamSet& p, size_t n, const uint8_t* ek, const uint8_t* m, uint8_t* c, uint8_t* Kout,
+                       const Workspace& ws) {
+    for (size_t h0 = 0; h0 < n; h0 += ws.hcap) {
+        const size_t hn = min_sz(ws.hcap, n - h0);
+        launch("k_hash_encaps", k_hash_encaps<K>, ceil_div(hn, WAVE), WAVE, st, hn, ek + h0 * p.ek_len, m + h0 * 32, Kout + h0 * 32, ws.r);
+        for (size_t c0 = 0; c0 < hn; c0 += ws.cap) {
+            const size_t cn = min_sz(ws.cap, hn - c0), i0 = h0 + c0;
+            const uint8_t* eki = ek + i0 * p.ek_len;
+            launch_sample(st, p, cn, eki + 384 * K, p.ek_len, /*transpose=*/1, ws.r + c0 * 32, 2 * K + 1, K, ws);
+            launch("k_encrypt", k_encrypt<K, ETA1, DU, DV, false>, ceil_div(cn, ARITH_WAVES), WAVE * ARITH_WAVES, st, cn, eki,
+                   (size_t)p.ek_len, m + i0 * 32, (const uint16_t*)ws.A, (const uint8_t*)ws.prf, c + i0 * p.c_len,
+                   (const uint8_t*)nullptr, (const uint8_t*)nullptr, (const uint8_t*)nullptr, (uint8_t*)nullptr);
+        }
+    }
 }
 
 // ---- KEM_Decaps / Decaps_internal (ml_kem.c:1310-1359, :1136-1225) -------------------------------
 // hash_check = true reproduces the public KEM_Decaps: status[i] = -5 when H(dk.ek) != dk.h (K[i] is then
 // still the Decaps_internal result; the host shim discards it like the reference does).
 template <int K, int ETA1, int DU, int DV>
-inline void decaps_chunk(stream_t st, const ParamSet& p, size_t n, const uint8_t* dk, const uint8_t* c, uint8_t* Kout,
-                         int32_t* status, bool hash_check, const Workspace& ws) {
+inline void decaps_run(stream_t st, const ParamSet& p, size_t n, const uint8_t* dk, const uint8_t* c, uint8_t* Kout,
+                       int32_t* status, bool hash_check, const Workspace& ws) {
     constexpr int CLEN = 32 * (DU * K + DV);
-    launch("k_decrypt", k_decrypt<K, DU, DV>, ceil_div(n, ARITH_WAVES), WAVE * ARITH_WAVES, st, n, dk, (size_t)p.dk_len, c, ws.m);
-    if (hash_check)
-        launch("k_hash_decaps", k_hash_decaps<K, CLEN, true>, ceil_div(n, WAVE), WAVE, st, n, dk, c, (const uint8_t*)ws.m, ws.Kp, ws.r, ws.Kbar, status);
-    else
-        launch("k_hash_decaps", k_hash_decaps<K, CLEN, false>, ceil_div(n, WAVE), WAVE, st, n, dk, c, (const uint8_t*)ws.m, ws.Kp, ws.r, ws.Kbar, status);
-    launch_sample(st, p, n, dk + 768 * K, p.dk_len, /*transpose=*/1, ws.r, 2 * K + 1, K, ws);
-    launch("k_encrypt_cmp", k_encrypt<K, ETA1, DU, DV, true>, ceil_div(n, ARITH_WAVES), WAVE * ARITH_WAVES, st, n, dk + 384 * K, (size_t)p.dk_len,
-           (const uint8_t*)ws.m, (const uint16_t*)ws.A, (const uint8_t*)ws.prf, (uint8_t*)nullptr, c, (const uint8_t*)ws.Kp,
-           (const uint8_t*)ws.Kbar, Kout);
+    for (size_t h0 = 0; h0 < n; h0 += ws.hcap) {
+        const size_t hn = min_sz(ws.hcap, n - h0);
+        const uint8_t* dkh = dk + h0 * p.dk_len;
+        const uint8_t* ch = c + h0 * p.c_len;
+        launch("k_decrypt", k_decrypt<K, DU, DV>, ceil_div(hn, ARITH_WAVES), WAVE * ARITH_WAVES, st, hn, dkh, (size_t)p.dk_len, ch, ws.m);
+        if (hash_check)
+            launch("k_hash_decaps", k_hash_decaps<K, CLEN, true>, ceil_div(hn, WAVE), WAVE, st, hn, dkh, ch, (const uint8_t*)ws.m, ws.Kp,
+                   ws.r, ws.Kbar, status ? status + h0 : nullptr);
+        else
+            launch("k_hash_decaps", k_hash_decaps<K, CLEN, false>, ceil_div(hn, WAVE), WAVE, st, hn, dkh, ch, (const uint8_t*)ws.m, ws.Kp,
+                   ws.r, ws.Kbar, (int32_t*)nullptr);
+        for (size_t c0 = 0; c0 < hn; c0 += ws.cap) {
+            const size_t cn = min_sz(ws.cap, hn - c0), i0 = h0 + c0;
+            const uint8_t* dki = dk + i0 * p.dk_len;
+            launch_sample(st, p, cn, dki + 768 * K, p.dk_len, /*transpose=*/1, ws.r + c0 * 32, 2 * K + 1, K, ws);
+            launch("k_encrypt_cmp", k_encrypt<K, ETA1, DU, DV, true>, ceil_div(cn, ARITH_WAVES), WAVE * ARITH_WAVES, st, cn,
+                   dki + 384 * K, (size_t)p.dk_len, (const uint8_t*)(ws.m + c0 * 32), (const uint16_t*)ws.A, (const uint8_t*)ws.prf,
+                   (uint8_t*)nullptr, c + i0 * p.c_len, (const uint8_t*)(ws.Kp + c0 * 32), (const uint8_t*)(ws.Kbar + c0 * 32),
+                   Kout + i0 * 32);
+        }
+    }
 }
 
 inline int keygen_dispatch(stream_t st, int set, size_t n, const uint8_t* d, const uint8_t* z, uint8_t* ek, uint8_t* dk,
@@ -141,9 +200,9 @@ inline int keygen_dispatch(stream_t st, int set, size_t n, const uint8_t* d, con
     ParamSet p;
     if (!param_set(set, p)) return -1;
     switch (set) {
-    case 512: keygen_chunk<2, 3>(st, p, n, d, z, ek, dk, ws); break;
-    case 768: keygen_chunk<3, 2>(st, p, n, d, z, ek, dk, ws); break;
-    default: keygen_chunk<4, 2>(st, p, n, d, z, ek, dk, ws); break;
+    case 512: keygen_run<2, 3>(st, p, n, d, z, ek, dk, ws); break;
+    case 768: keygen_run<3, 2>(st, p, n, d, z, ek, dk, ws); break;
+    default: keygen_run<4, 2>(st, p, n, d, z, ek, dk, ws); break;
     }
     return 0;
 }
@@ -152,9 +211,9 @@ inline int encaps_dispatch(stream_t st, int set, size_t n, const uint8_t* ek, co
     ParamSet p;
     if (!param_set(set, p)) return -1;
     switch (set) {
-    case 512: encaps_chunk<2, 3, 10, 4>(st, p, n, ek, m, c, K, ws); break;
-    case 768: encaps_chunk<3, 2, 10, 4>(st, p, n, ek, m, c, K, ws); break;
-    default: encaps_chunk<4, 2, 11, 5>(st, p, n, ek, m, c, K, ws); break;
+    case 512: encaps_run<2, 3, 10, 4>(st, p, n, ek, m, c, K, ws); break;
+    case 768: encaps_run<3, 2, 10, 4>(st, p, n, ek, m, c, K, ws); break;
+    default: encaps_run<4, 2, 11, 5>(st, p, n, ek, m, c, K, ws); break;
     }
     return 0;
 }
@@ -163,9 +222,9 @@ inline int decaps_dispatch(stream_t st, int set, size_t n, const uint8_t* dk, co
     ParamSet p;
     if (!param_set(set, p)) return -1;
     switch (set) {
-    case 512: decaps_chunk<2, 3, 10, 4>(st, p, n, dk, c, K, status, hash_check, ws); break;
-    case 768: decaps_chunk<3, 2, 10, 4>(st, p, n, dk, c, K, status, hash_check, ws); break;
-    default: decaps_chunk<4, 2, 11, 5>(st, p, n, dk, c, K, status, hash_check, ws); break;
+    case 512: decaps_run<2, 3, 10, 4>(st, p, n, dk, c, K, status, hash_check, ws); break;
+    case 768: decaps_run<3, 2, 10, 4>(st, p, n, dk, c, K, status, hash_check, ws); break;
+    default: decaps_run<4, 2, 11, 5>(st, p, n, dk, c, K, status, hash_check, ws); break;
     }
     return 0;
 }
@@ -189,6 +248,7 @@ inline int cbd_launch(stream_t st, int eta, size_t n, const uint8_t* bytes, uint
     else return -1;
     return 0;
 }
+// stand-alone SampleNTT over explicit 34-byte seeds: the general kernel in direct mode
 inline void sample_ntt_launch(stream_t st, size_t n, const uint8_t* seeds34, uint16_t* out) {
     SampleArgs a{};
     a.n_xof = n; a.rho = seeds34; a.rho_stride = 34; a.K = 0; a.A = out;
@@ -203,7 +263,7 @@ inline int prf_launch(stream_t st, int eta, size_t n, const uint8_t* in33, uint8
     return 0;
 }
 inline int hash_launch(stream_t st, int kind, size_t n, const uint8_t* msg, unsigned len, size_t stride, uint8_t* out) {
-    if (kind < 0 || kind > 2 || (stride & 3) || stride < len) return -1;   // rows must start 4-byte aligned
+    if (kind < 0 || kind > 2 || (stride & 7) || stride < len) return -1;   // rows must start 8-byte aligned
     launch("k_hash_batch", k_hash_batch, ceil_div(n, WAVE), WAVE, st, n, kind, msg, len, stride, out);
     return 0;
 }

@@ -1,0 +1,173 @@
+// mlkem_sampler.hpp — the fast path of SampleNTT / PRF sampling (ml_kem.c:189-245, :496-515).
+//
+// k_sample_main : every XOF lane squeezes exactly THREE SHAKE128 blocks (336 candidates, mean 273 accepted);
+//                 the ~0.8 % of sponges that still miss coefficients are appended to a leftover list and
+//                 finished by the general kernel k_sample (mlkem_kernels.hpp) in a second, tiny launch.  Without
+//                 this split ~40 % of the waves would run a 4th permutation for the sake of one or two lanes.
+//                 Blocks 0 and 1 can never complete a polynomial (2 x 112 < 256), so their rejection loop
+//                 carries no `count < 256` test and writes unconditionally (rejected values are overwritten).
+//                 The per-lane LDS ring holds RING coefficients and is flushed in aligned RING/2-coefficient
+//                 chunks at NFLUSH points per block (RING = 64: 9 KB per wave, 64-byte chunks, 4 lanes x 16 B).
+//                 PRF lanes: one permutation (two for eta = 3), raw bytes out.
+#pragma once
+#include "mlkem_kernels.hpp"
+
+namespace mlkem {
+
+template <int RING_N>
+struct RingCfg {
+    static constexpr int N = RING_N;                 // coefficients per lane ring (power of two)
+    static constexpr int CHUNK = RING_N / 2;         // coefficients per flushed chunk
+    static constexpr int STRIDE = RING_N + 8;        // int16 per row (16-byte aligned rows, skewed banks)
+    static constexpr int LPC = CHUNK / 8;            // lanes per chunk (16 B each)
+    static constexpr int PPS = WAVE / LPC;           // polynomials per flush step
+    static constexpr int STEPS = WAVE / PPS;         // flush steps to cover the 64 lanes
+};
+
+// flush every completed chunk (at most one per lane per call)
+template <class R>
+__device__ __forceinline__ void ring_flush_t(const int16_t* ring, uint16_t* A, size_t g, size_t n_xof, int cnt, int& flushed) {
+    const int l = lane_id();
+    const int has = (cnt - flushed >= R::CHUNK) && (g < n_xof);
+    if (__ballot(has) == 0) return;
+    const int grp = l / R::LPC, sub = l % R::LPC;
+#pragma unroll 1
+    for (int step = 0; step < R::STEPS; step++) {
+        const int p = step * R::PPS + grp;
+        const int p_has = __shfl(has, p);
+        const int p_flushed = __shfl(flushed, p);
+        if (p_has) {
+            const int16_t* src = ring + p * R::STRIDE + (p_flushed & (R::N - 1)) + sub * 8;
+            const uint4 v = *reinterpret_cast<const uint4*>(src);
+            const size_t gp = g - (size_t)l + (size_t)p;
+            *reinterpret_cast<uint4*>(A + gp * 256 + p_flushed + sub * 8) = v;
+        }
+    }
+    if (has) flushed += R::CHUNK;
+}
+
+// one 3-byte group -> two candidates (ml_kem.c:208-219)
+#define MLKEM_T_FAST(v)                                                                   \
+    {                                                                                     \
+        const uint32_t d1 = (v) & 0xFFFu, d2 = (v) >> 12;                                 \
+        myring[cnt & (R::N - 1)] = (int16_t)d1; cnt += d1 < (uint32_t)KQ ? 1 : 0;         \
+        myring[cnt & (R::N - 1)] = (int16_t)d2; cnt += d2 < (uint32_t)KQ ? 1 : 0;         \
+    }
+#define MLKEM_T_GUARD(v)                                                                  \
+    {                                                                                     \
+        const uint32_t d1 = (v) & 0xFFFu, d2 = (v) >> 12;                                 \
+        if (d1 < (uint32_t)KQ && cnt < 256) { myring[cnt & (R::N - 1)] = (int16_t)d1; cnt++; } \
+        if (d2 < (uint32_t)KQ && cnt < 256) { myring[cnt & (R::N - 1)] = (int16_t)d2; cnt++; } \
+    }
+// triples FIRST..LAST-1 (0..3) of the 12-byte group starting at state dword W0
+#define MLKEM_G(T, W0, FIRST, LAST)                                                                       \
+    {                                                                                                     \
+        const uint32_t w0 = keccak_word<W0>(s), w1 = keccak_word<W0 + 1>(s), w2 = keccak_word<W0 + 2>(s); \
+        if (FIRST <= 0 && LAST > 0) T(w0 & 0xFFFFFFu)                                                     \
+        if (FIRST <= 1 && LAST > 1) T((w0 >> 24) | ((w1 & 0xFFFFu) << 8))                                 \
+        if (FIRST <= 2 && LAST > 2) T((w1 >> 16) | ((w2 & 0xFFu) << 16))                                  \
+        if (FIRST <= 3 && LAST > 3) T(w2 >> 8)                                                            \
+    }
+#define MLKEM_FLUSH()                                               \
+    wave_lds_fence();                                               \
+    ring_flush_t<R>(ring, a.A, g, a.n_xof, cnt, flushed);           \
+    wave_lds_fence();
+
+// the 56 triples of one squeezed block, with NFLUSH = 4 (quarters of 14 triples) or 2 (halves of 28) flush points
+#define MLKEM_BLOCK(T)                                                                                      \
+    MLKEM_G(T, 0, 0, 4) MLKEM_G(T, 3, 0, 4) MLKEM_G(T, 6, 0, 4) MLKEM_G(T, 9, 0, 2)                         \
+    if (R::N < 128) { MLKEM_FLUSH() }                                                                       \
+    MLKEM_G(T, 9, 2, 4) MLKEM_G(T, 12, 0, 4) MLKEM_G(T, 15, 0, 4) MLKEM_G(T, 18, 0, 4)                      \
+    MLKEM_FLUSH()                                                                                           \
+    MLKEM_G(T, 21, 0, 4) MLKEM_G(T, 24, 0, 4) MLKEM_G(T, 27, 0, 4) MLKEM_G(T, 30, 0, 2)                     \
+    if (R::N < 128) { MLKEM_FLUSH() }                                                                       \
+    MLKEM_G(T, 30, 2, 4) MLKEM_G(T, 33, 0, 4) MLKEM_G(T, 36, 0, 4) MLKEM_G(T, 39, 0, 4)                     \
+    MLKEM_FLUSH()
+
+template <int RING_N>
+__global__ void __launch_bounds__(WAVE) k_sample_main(SampleArgs a) {
+    using R = RingCfg<RING_N>;
+    __shared__ __attribute__((aligned(16))) int16_t ring[WAVE * R::STRIDE];
+    const int l = lane_id();
+    KeccakState s;
+    if (blockIdx.x < a.xof_blocks) {
+        // ---------------- XOF role: three blocks, no data-dependent control flow ----------------
+        const size_t g = (size_t)blockIdx.x * WAVE + l;
+        const size_t gc = g < a.n_xof ? g : a.n_xof - 1;
+        uint32_t seed[8];
+        const size_t kk = (size_t)(a.K * a.K), item = gc / kk;
+        const unsigned e = (unsigned)(gc - item * kk), ra = e / (unsigned)a.K, cb = e - ra * (unsigned)a.K;
+        load32(a.rho, a.rho_stride, item, seed);
+        const unsigned i0 = a.transpose ? ra : cb, i1 = a.transpose ? cb : ra;
+        int16_t* myring = ring + l * R::STRIDE;
+        int cnt = 0, flushed = 0;
+        keccak_zero(s);
+        MLKEM_SET_WORDS8(s, 0, seed)
+        keccak_xor_byte<32>(s, i0);
+        keccak_xor_byte<33>(s, i1);
+        keccak_xor_byte<34>(s, 0x1F);
+        keccak_xor_byte<167>(s, 0x80);
+        keccak_f1600(s);
+        MLKEM_BLOCK(MLKEM_T_FAST)
+        keccak_f1600(s);
+        MLKEM_BLOCK(MLKEM_T_FAST)
+        keccak_f1600(s);
+        MLKEM_BLOCK(MLKEM_T_GUARD)
+        if (cnt < 256 && g < a.n_xof) {   // ~0.8 % of sponges: finished by k_sample in list mode
+            const uint32_t idx = atomicAdd(&a.leftover[0], 1u);
+            a.leftover[1 + idx] = (uint32_t)g;
+        }
+    } else {
+        // ---------------- PRF role (ml_kem.c:496-515; SHAKE128 in the reference) ----------------
+        const size_t g = (size_t)(blockIdx.x - a.xof_blocks) * WAVE + l;
+        const size_t gc = g < a.n_prf ? g : a.n_prf - 1;
+        uint32_t seed[8];
+        const size_t item = gc / (size_t)a.per_item;
+        const unsigned ctr = (unsigned)(gc - item * (size_t)a.per_item);
+        load32(a.r, 32, item, seed);
+        const unsigned eta = (int)ctr < a.n_eta1 ? (unsigned)a.eta1 : 2u;
+        keccak_zero(s);
+        MLKEM_SET_WORDS8(s, 0, seed)
+        keccak_xor_byte<32>(s, ctr);
+        keccak_xor_byte<33>(s, 0x1F);
+        keccak_xor_byte<167>(s, 0x80);
+        keccak_f1600(s);
+        // stage the 128 (or 168) bytes of every lane in LDS and write them out as 16 B per lane, 8 lanes per row
+        uint32_t* st32 = reinterpret_cast<uint32_t*>(ring);   // 64 rows x 33 dwords (odd stride: conflict-free)
+#define MLKEM_SW(W) st32[l * 33 + W] = keccak_word<W>(s);
+        MLKEM_SW(0) MLKEM_SW(1) MLKEM_SW(2) MLKEM_SW(3) MLKEM_SW(4) MLKEM_SW(5) MLKEM_SW(6) MLKEM_SW(7)
+        MLKEM_SW(8) MLKEM_SW(9) MLKEM_SW(10) MLKEM_SW(11) MLKEM_SW(12) MLKEM_SW(13) MLKEM_SW(14) MLKEM_SW(15)
+        MLKEM_SW(16) MLKEM_SW(17) MLKEM_SW(18) MLKEM_SW(19) MLKEM_SW(20) MLKEM_SW(21) MLKEM_SW(22) MLKEM_SW(23)
+        MLKEM_SW(24) MLKEM_SW(25) MLKEM_SW(26) MLKEM_SW(27) MLKEM_SW(28) MLKEM_SW(29) MLKEM_SW(30) MLKEM_SW(31)
+#undef MLKEM_SW
+        wave_lds_fence();
+        const size_t g0 = g - (size_t)l;
+#pragma unroll
+        for (int it = 0; it < 8; it++) {
+            const int f = it * WAVE + l, row = f >> 3, q = f & 7;   // row = lane whose output is written, q = 16-byte piece
+            if (g0 + row < a.n_prf) {
+                uint4 v;
+                v.x = st32[row * 33 + 4 * q]; v.y = st32[row * 33 + 4 * q + 1];
+                v.z = st32[row * 33 + 4 * q + 2]; v.w = st32[row * 33 + 4 * q + 3];
+                *reinterpret_cast<uint4*>(a.prf + (g0 + row) * a.prf_stride + 16 * q) = v;
+            }
+        }
+        if (__ballot(eta == 3) != 0) {   // eta = 3: bytes 128..167 of this block + 24 bytes of the next
+            uint32_t* out = reinterpret_cast<uint32_t*>(a.prf + gc * a.prf_stride);
+            const bool mine = g < a.n_prf && eta == 3;
+            if (mine) {
+                out[32] = keccak_word<32>(s); out[33] = keccak_word<33>(s); out[34] = keccak_word<34>(s);
+                out[35] = keccak_word<35>(s); out[36] = keccak_word<36>(s); out[37] = keccak_word<37>(s);
+                out[38] = keccak_word<38>(s); out[39] = keccak_word<39>(s); out[40] = keccak_word<40>(s);
+                out[41] = keccak_word<41>(s);
+            }
+            keccak_f1600(s);
+            if (mine) {
+                out[42] = keccak_word<0>(s); out[43] = keccak_word<1>(s); out[44] = keccak_word<2>(s);
+                out[45] = keccak_word<3>(s); out[46] = keccak_word<4>(s); out[47] = keccak_word<5>(s);
+            }
+        }
+    }
+}
+
+}   // namespace mlkem

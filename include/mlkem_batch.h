@@ -97,7 +97,7 @@ int mlkem_sample_cbd_dev(mlkem_ctx* ctx, int eta, size_t n, const uint8_t* bytes
 /* replaces PRF(s, b, eta)      ml_kem.c:496-515 (SHAKE128!) ; in : n x 33 bytes (s || b) ; out : n x 64*eta */
 int mlkem_prf_dev(mlkem_ctx* ctx, int eta, size_t n, const uint8_t* in33, uint8_t* out, void* stream);
 /* replaces H / G / J           ml_kem.c:521-572 on n equal-length messages; message i starts at
- * msg + i*stride (stride % 4 == 0, stride >= len).  kind: 0 = H (32 B out), 1 = G (64 B), 2 = J (32 B, SHAKE128) */
+ * msg + i*stride (stride % 8 == 0, stride >= len).  kind: 0 = H (32 B out), 1 = G (64 B), 2 = J (32 B, SHAKE128) */
 int mlkem_hash_dev(mlkem_ctx* ctx, int kind, size_t n, const uint8_t* msg, unsigned len, size_t stride, uint8_t* out, void* stream);
 
 /* ---- batched KEM, host pointers (stage + run + synchronise) ---------------------------------------- */

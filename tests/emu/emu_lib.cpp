@@ -1,5 +1,6 @@
 // tests/emu/emu_lib.cpp — TEST INFRASTRUCTURE ONLY: the product's kernels + pipeline compiled for the
 // host wave emulator (hip_emu.hpp) and exported with the same call shapes as the C-ABI device entry points.
+// `cap`/`hcap`/`ring` let the tests exercise the chunk / h-chunk loops and both sampler ring sizes.
 #include "hip_emu.hpp"
 
 #include "../../crystals-kyber_amd/csrc/mlkem_pipeline.hpp"
@@ -8,23 +9,33 @@
 
 using namespace mlkem;
 
+static size_t g_cap = 0, g_hcap = 0;
+static int g_ring = 64;
+
+static void* xalloc(size_t bytes) { return aligned_alloc(64, (bytes + 127) / 64 * 64); }
+
 static Workspace make_ws(size_t n) {
     Workspace ws;
-    ws.A = (uint16_t*)aligned_alloc(64, (n * 16 * 512 + 63) / 64 * 64 + 64);
-    ws.prf = (uint8_t*)aligned_alloc(64, n * 9 * 192 + 64);
-    ws.r = (uint8_t*)aligned_alloc(64, n * 32 + 64);
-    ws.rho = (uint8_t*)aligned_alloc(64, n * 32 + 64);
-    ws.m = (uint8_t*)aligned_alloc(64, n * 32 + 64);
-    ws.Kp = (uint8_t*)aligned_alloc(64, n * 32 + 64);
-    ws.Kbar = (uint8_t*)aligned_alloc(64, n * 32 + 64);
-    ws.cap_items = n;
+    ws.cap = g_cap ? g_cap : (n ? n : 1);
+    ws.hcap = g_hcap ? g_hcap : (n ? n : 1);
+    if (ws.hcap < ws.cap) ws.hcap = ws.cap;
+    ws.ring = g_ring;
+    ws.A = (uint16_t*)xalloc(ws.cap * 16 * 512);
+    ws.prf = (uint8_t*)xalloc(ws.cap * 9 * 192);
+    ws.leftover = (uint32_t*)xalloc((ws.cap * 16 + 1) * 4);
+    ws.r = (uint8_t*)xalloc(ws.hcap * 32);
+    ws.rho = (uint8_t*)xalloc(ws.hcap * 32);
+    ws.m = (uint8_t*)xalloc(ws.hcap * 32);
+    ws.Kp = (uint8_t*)xalloc(ws.hcap * 32);
+    ws.Kbar = (uint8_t*)xalloc(ws.hcap * 32);
     return ws;
 }
 static void free_ws(Workspace& ws) {
-    free(ws.A); free(ws.prf); free(ws.r); free(ws.rho); free(ws.m); free(ws.Kp); free(ws.Kbar);
+    free(ws.A); free(ws.prf); free(ws.leftover); free(ws.r); free(ws.rho); free(ws.m); free(ws.Kp); free(ws.Kbar);
 }
 
 extern "C" {
+void emu_config(size_t cap, size_t hcap, int ring) { g_cap = cap; g_hcap = hcap; g_ring = ring == 128 ? 128 : 64; }
 int emu_keygen(int set, size_t n, const uint8_t* d, const uint8_t* z, uint8_t* ek, uint8_t* dk) {
     Workspace ws = make_ws(n);
     int rc = keygen_dispatch(nullptr, set, n, d, z, ek, dk, ws);
@@ -50,5 +61,20 @@ void emu_sample_ntt(size_t n, const uint8_t* seeds, uint16_t* out) { sample_ntt_
 int emu_prf(int eta, size_t n, const uint8_t* in33, uint8_t* out) { return prf_launch(nullptr, eta, n, in33, out); }
 int emu_hash(int kind, size_t n, const uint8_t* msg, unsigned len, size_t stride, uint8_t* out) {
     return hash_launch(nullptr, kind, n, msg, len, stride, out);
+}
+// SampleNTT of a k x k matrix through the production path (three-block main kernel + leftover pass);
+// returns the number of sponges that went through the leftover list.
+int emu_sample_matrix(int k, size_t n, const uint8_t* rho, int transpose, uint16_t* A_out) {
+    Workspace ws = make_ws(n);
+    ParamSet p;
+    param_set(k == 2 ? 512 : k == 3 ? 768 : 1024, p);
+    uint8_t* r = (uint8_t*)xalloc(n * 32);
+    for (size_t i = 0; i < n * 32; i++) r[i] = (uint8_t)i;
+    launch_sample(nullptr, p, n, rho, 32, transpose, r, 2 * k + 1, k, ws);
+    memcpy(A_out, ws.A, n * (size_t)(k * k) * 512);
+    int left = (int)ws.leftover[0];
+    free(r);
+    free_ws(ws);
+    return left;
 }
 }

@@ -98,3 +98,4 @@ inline int __shfl(int v, int src) {
 }
 inline int __shfl_xor(int v, int mask) { return __shfl(v, (int)((threadIdx.x & 63) ^ (unsigned)mask)); }
 inline uint32_t atomicOr(uint32_t* p, uint32_t v) { return __atomic_fetch_or(p, v, __ATOMIC_RELAXED); }
+inline uint32_t atomicAdd(uint32_t* p, uint32_t v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }

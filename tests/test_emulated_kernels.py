@@ -64,7 +64,7 @@ def test_emu_hashes_all_block_boundaries(emu, oracle):
     for kind, fn, ol in ((0, oracle.H, 32), (1, oracle.G, 64), (2, oracle.J, 32)):
         for ln in (0, 1, 3, 4, 33, 64, 71, 72, 73, 135, 136, 137, 167, 168, 169, 800, 1120, 1184):
             n = 65
-            stride = (ln + 3) // 4 * 4 + 4
+            stride = (ln + 7) // 8 * 8 + 8
             msg = rng.integers(0, 256, (n, stride)).astype(np.uint8)
             out = np.zeros((n, ol), np.uint8)
             assert emu.emu_hash(kind, C.c_size_t(n), p8(msg), ln, C.c_size_t(stride), p8(out)) == 0
@@ -101,3 +101,47 @@ def test_emu_kem_matches_oracle_and_golden(emu, oracle, golden, pset):
     assert (Kd[sto == 0] == Ko[sto == 0]).all()
     assert bytes(Kd[0]).hex() == g["K_reject_c5_xor1"]
     assert (Kd[1] == K[1]).all() and (Kd[4] == K[4]).all() and not (Kd[3] == K[3]).all()
+
+
+@pytest.mark.parametrize("ring", (64, 128))
+def test_emu_matrix_sampler_with_leftover_pass(emu, oracle, ring):
+    """Production SampleNTT path: three-block main kernel + general kernel over the leftover list.  With 576
+    sponges about 0.8 % (4-5) need a 4th squeeze block; the test requires that the leftover path was taken."""
+    emu.emu_config(C.c_size_t(0), C.c_size_t(0), ring)
+    k, n = 3, 64
+    rho = seeds("emu-rho", n, 31 + ring)
+    A = np.zeros((n, k * k, 256), np.uint16)
+    left = emu.emu_sample_matrix(k, C.c_size_t(n), p8(rho), 1, p16(A))
+    emu.emu_config(C.c_size_t(0), C.c_size_t(0), 64)
+    assert left >= 1, "seed set must exercise the leftover list"
+    for i in range(n):
+        for a in range(k):
+            for b in range(k):
+                seed = np.concatenate([rho[i], [a, b]]).astype(np.uint8)   # Encrypt order: B[32] = row, B[33] = col
+                assert (A[i, a * k + b] == oracle.sample_ntt(seed)).all(), (i, a, b)
+    assert A.max() < 3329
+
+
+def test_emu_chunk_and_hchunk_loops(emu, oracle):
+    """cap = 3 items per chunk, hcap = 7 items per h-chunk, 17 items: every loop boundary is crossed."""
+    emu.emu_config(C.c_size_t(3), C.c_size_t(7), 64)
+    try:
+        pset, n = 768, 17
+        ekl, dkl, cl = SIZES[pset]
+        d, z, m = seeds("emu-cd", n, 9), seeds("emu-cz", n, 9), seeds("emu-cm", n, 9)
+        ek, dk = np.zeros((n, ekl), np.uint8), np.zeros((n, dkl), np.uint8)
+        assert emu.emu_keygen(pset, C.c_size_t(n), p8(d), p8(z), p8(ek), p8(dk)) == 0
+        ek_o, dk_o = oracle.keygen(pset, d, z)
+        assert (ek == ek_o).all() and (dk == dk_o).all()
+        c, K = np.zeros((n, cl), np.uint8), np.zeros((n, 32), np.uint8)
+        assert emu.emu_encaps(pset, C.c_size_t(n), p8(ek), p8(m), p8(c), p8(K)) == 0
+        c_o, K_o = oracle.encaps(pset, ek, m)
+        assert (c == c_o).all() and (K == K_o).all()
+        cb = c.copy()
+        cb[[2, 8, 16], [0, 500, 1087]] ^= 1
+        Kd, st = np.zeros((n, 32), np.uint8), np.zeros(n, np.int32)
+        assert emu.emu_decaps(pset, C.c_size_t(n), p8(dk), p8(cb), p8(Kd), st.ctypes.data_as(C.POINTER(C.c_int32)), 1) == 0
+        Ko, sto = oracle.decaps(pset, dk, cb)
+        assert (st == 0).all() and (sto == 0).all() and (Kd == Ko).all()
+    finally:
+        emu.emu_config(C.c_size_t(0), C.c_size_t(0), 64)
