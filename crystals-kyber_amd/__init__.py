@@ -16,7 +16,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libmlkem_amd.so")
+LIB_PATH = os.environ.get("MLKEM_LIB_PATH") or os.path.join(HERE, "libmlkem_amd.so")   # override: A/B builds in experiments
 SHIM_PATH = os.path.join(HERE, "libml_kem.so")
 
 SIZES = {512: (800, 1632, 768), 768: (1184, 2400, 1088), 1024: (1568, 3168, 1568)}  # ek, dk, c (ml_kem.h:52-59)

@@ -1,0 +1,436 @@
+// mlkem_arith.hpp — wave-per-instance polynomial kernels: K-PKE KeyGen / Encrypt / Decrypt (ml_kem.c:651-1023) after
+// hashing and sampling, plus the stand-alone NTT / MultiplyNTTs / CBD primitives.
+//
+// One wavefront owns one KEM instance (or one polynomial); each lane holds 4 coefficients (NAT layout: 4l..4l+3,
+// which is also the base-case-multiply pair layout and the HBM layout).  Modular arithmetic runs exactly on the
+// fp32 pipe (mlkem_fntt.hpp); Compress / ByteEncode / ByteDecode are integer work on a wave-private LDS byte buffer.
+// No workgroup barrier is used: the 4 waves of a workgroup are independent.
+//
+// Memory-latency structure (profiles/r01_pmc_arith.txt: 57 % of a wave's life was s_waitcnt): the wave-LDS fences are
+// compiler barriers, so a load written next to its use is issued next to its use.  Every kernel therefore issues ALL
+// of its prologue loads (PRF bytes, packed key / ciphertext polynomials, message bits) before the first NTT, and the
+// rows of the sampled matrix are double-buffered: row a+1 is requested before row a is consumed.
+#pragma once
+#include "mlkem_fntt.hpp"
+
+namespace mlkem {
+
+constexpr int ARITH_WAVES = 4;   // waves per workgroup (each fully independent)
+#ifndef MLKEM_ARITH_MINWAVES
+#define MLKEM_ARITH_MINWAVES 1   // __launch_bounds__ second argument of the K-PKE kernels (register budget knob)
+#endif
+
+template <int K>
+struct __attribute__((aligned(16))) ArithLds {
+    float xch[256];         // NTT exchange buffer
+    float vhat[K][256];     // NTT-domain vector (y-hat or s-hat), reduced
+    float vgam[K][128];     // its odd coefficients times gamma (ml_kem.c:402-403)
+    uint32_t cbuf[CODEC_BUF_WORDS];
+};
+
+__device__ __forceinline__ void store_poly_nat(uint16_t* p, const int (&x)[4]) {
+    uint2 v;
+    v.x = ((uint32_t)x[0] & 0xFFFFu) | ((uint32_t)x[1] << 16);
+    v.y = ((uint32_t)x[2] & 0xFFFFu) | ((uint32_t)x[3] << 16);
+    *reinterpret_cast<uint2*>(p + 4 * lane_id()) = v;
+}
+__device__ __forceinline__ uint2 load_poly_raw(const uint16_t* p) { return *reinterpret_cast<const uint2*>(p + 4 * lane_id()); }
+__device__ __forceinline__ void poly_raw_to_f(const uint2 v, float (&x)[4]) {
+    x[0] = (float)(v.x & 0xFFFFu); x[1] = (float)(v.x >> 16);
+    x[2] = (float)(v.y & 0xFFFFu); x[3] = (float)(v.y >> 16);
+}
+
+// ---- SamplePolyCBD (ml_kem.c:253-275), split into the load of the lane's 8*ETA bits and their evaluation --------
+template <int ETA>
+__device__ __forceinline__ uint32_t cbd_load(const uint8_t* prf) {
+    const int l = lane_id();
+    if constexpr (ETA == 2) return *reinterpret_cast<const uint16_t*>(prf + 2 * l);   // 4 coefficients = 16 bits
+    else return (uint32_t)prf[3 * l] | ((uint32_t)prf[3 * l + 1] << 8) | ((uint32_t)prf[3 * l + 2] << 16);   // 24 bits
+}
+template <int ETA>
+__device__ __forceinline__ void cbd_eval_f(uint32_t t, float (&x)[4]) {
+    if constexpr (ETA == 2) {
+        const uint32_t d = (t & 0x5555u) + ((t >> 1) & 0x5555u);   // pairwise bit sums
+#pragma unroll
+        for (int m = 0; m < 4; m++) x[m] = (float)((int)((d >> (4 * m)) & 3u) - (int)((d >> (4 * m + 2)) & 3u));
+    } else {
+        const uint32_t d = (t & 0x249249u) + ((t >> 1) & 0x249249u) + ((t >> 2) & 0x249249u);   // 3-bit group sums
+#pragma unroll
+        for (int m = 0; m < 4; m++) x[m] = (float)((int)((d >> (6 * m)) & 7u) - (int)((d >> (6 * m + 3)) & 7u));
+    }
+}
+
+// ---- packed-polynomial bytes held in registers between the (early) load and the (late) decode -------------------
+template <int D>
+struct CodecRegs {
+    static constexpr int NW = (8 * D + 63) / 64;   // dwords per lane: 32*D bytes = 8*D dwords over 64 lanes
+    uint32_t w[NW];
+};
+template <int D>
+__device__ __forceinline__ void codec_fetch(const uint8_t* g, CodecRegs<D>& r) {
+    const int l = lane_id();
+    const uint32_t* gw = reinterpret_cast<const uint32_t*>(g);
+#pragma unroll
+    for (int i = 0; i < CodecRegs<D>::NW; i++) r.w[i] = (l + 64 * i < 8 * D) ? gw[l + 64 * i] : 0u;
+}
+// ByteDecode_D (+ optional Decompress_D) (ml_kem.c:153-177, :104-119) of pre-fetched bytes -> 4 floats per lane
+template <int D, bool DECOMPRESS>
+__device__ __forceinline__ void decode_regs(uint32_t* cbuf, const CodecRegs<D>& r, float (&x)[4]) {
+    const int l = lane_id();
+#pragma unroll
+    for (int i = 0; i < CodecRegs<D>::NW; i++)
+        if (l + 64 * i < 8 * D + 4) cbuf[l + 64 * i] = r.w[i];   // the 4 words past the end are zero (fetch masks them)
+    if (8 * D + 4 > 64 * CodecRegs<D>::NW && l < 4) cbuf[8 * D + l] = 0;
+    wave_lds_fence();
+    unsigned v[4];
+    codec_decode<D>(cbuf, v);
+    wave_lds_fence();
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+        if constexpr (DECOMPRESS) x[m] = (float)decompress_d<D>(v[m]);
+        else x[m] = (float)v[m];   // raw D-bit value: for D = 12 no reduction mod q (ml_kem.c:170, F3)
+    }
+}
+
+// Compress_D + ByteEncode_D (ml_kem.c:83-97, :125-145) of x (any representative, |x| <= 2^24), then either store the
+// 32*D bytes or compare them with the pre-fetched reference bytes
+template <int D, bool COMPARE>
+__device__ __forceinline__ uint32_t emit_compressed(uint32_t* cbuf, const float (&x)[4], uint8_t* out, const CodecRegs<D>& ref) {
+    unsigned v[4];
+#pragma unroll
+    for (int m = 0; m < 4; m++) v[m] = compress_d<D>((unsigned)fcanon(x[m]));
+    codec_zero<D>(cbuf);
+    wave_lds_fence();
+    codec_encode<D>(cbuf, v);
+    wave_lds_fence();
+    uint32_t diff = 0;
+    if constexpr (COMPARE) {
+        const int l = lane_id();
+#pragma unroll
+        for (int i = 0; i < CodecRegs<D>::NW; i++)
+            if (l + 64 * i < 8 * D) diff |= cbuf[l + 64 * i] ^ ref.w[i];
+    } else {
+        codec_store_bytes<D>(cbuf, out);
+    }
+    wave_lds_fence();
+    return diff;
+}
+// ByteEncode_12 (ml_kem.c:736-756) of x (any representative) to one or two destinations
+__device__ __forceinline__ void emit_encode12(uint32_t* cbuf, const float (&x)[4], uint8_t* out0, uint8_t* out1) {
+    unsigned v[4];
+#pragma unroll
+    for (int m = 0; m < 4; m++) v[m] = (unsigned)fcanon(x[m]);
+    codec_zero<12>(cbuf);
+    wave_lds_fence();
+    codec_encode<12>(cbuf, v);
+    wave_lds_fence();
+    codec_store_bytes<12>(cbuf, out0);
+    if (out1) codec_store_bytes<12>(cbuf, out1);
+    wave_lds_fence();
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_encrypt — K-PKE.Encrypt (ml_kem.c:776-936) given A^T (sampler, XOF role) and the PRF bytes (PRF role).
+//   COMPARE = false : write c                                   (Encaps_internal, ml_kem.c:1127)
+//   COMPARE = true  : compare c' with c, K = (c == c') ? K' : Kbar (Decaps_internal, ml_kem.c:1206-1215)
+// ------------------------------------------------------------------------------------------------
+template <int K, int ETA1, int DU, int DV, bool COMPARE>
+__global__ void __launch_bounds__(WAVE * ARITH_WAVES, MLKEM_ARITH_MINWAVES)
+k_encrypt(size_t n, const uint8_t* __restrict__ ek, size_t ek_stride, const uint8_t* __restrict__ msg, const uint16_t* __restrict__ A,
+          const uint8_t* __restrict__ prf, uint8_t* __restrict__ c_out, const uint8_t* __restrict__ c_in, const uint8_t* __restrict__ Kp,
+          const uint8_t* __restrict__ Kbar, uint8_t* __restrict__ Kout) {
+    __shared__ ArithLds<K> lds_all[ARITH_WAVES];
+    const int wv = (int)(threadIdx.x >> 6), l = lane_id();
+    const size_t item = (size_t)blockIdx.x * ARITH_WAVES + wv;
+    if (item >= n) return;
+    ArithLds<K>& L = lds_all[wv];
+    constexpr unsigned PS = (ETA1 == 3) ? 192 : 128, CLEN = 32 * (DU * K + DV);
+    const uint8_t* my_prf = prf + item * (size_t)((2 * K + 1) * PS);
+    const uint8_t* my_ek = ek + item * ek_stride;
+    const uint16_t* my_A = A + item * (size_t)(K * K * 256);
+    uint8_t* my_c = COMPARE ? nullptr : c_out + item * CLEN;
+    const uint8_t* my_cin = COMPARE ? c_in + item * CLEN : nullptr;
+
+    // ---- prologue: every load whose address is known now ----
+    uint32_t raw_y[K], raw_e1[K], raw_e2;
+#pragma unroll
+    for (int b = 0; b < K; b++) raw_y[b] = cbd_load<ETA1>(my_prf + b * PS);
+    uint2 a_next[K];
+#pragma unroll
+    for (int b = 0; b < K; b++) a_next[b] = load_poly_raw(my_A + b * 256);   // row 0 of A^T
+#pragma unroll
+    for (int a = 0; a < K; a++) raw_e1[a] = cbd_load<2>(my_prf + (K + a) * PS);
+    raw_e2 = cbd_load<2>(my_prf + (2 * K) * PS);
+    CodecRegs<12> that[K];
+#pragma unroll
+    for (int b = 0; b < K; b++) codec_fetch<12>(my_ek + 384 * b, that[b]);
+    const unsigned mb = msg[item * 32 + (l >> 1)] >> (4 * (l & 1));   // the lane's 4 message bits
+    CodecRegs<DU> cu_ref[COMPARE ? K : 1];
+    CodecRegs<DV> cv_ref;
+    if constexpr (COMPARE) {
+#pragma unroll
+        for (int a = 0; a < K; a++) codec_fetch<DU>(my_cin + a * 32 * DU, cu_ref[a]);
+        codec_fetch<DV>(my_cin + K * 32 * DU, cv_ref);
+    }
+    NttTwiddlesF tw;
+    load_twiddles_f(tw);
+
+    uint32_t diff = 0;
+    float x[4];
+    // y-hat = NTT(CBD_eta1(PRF(r, n)))  n = 0..K-1   (ml_kem.c:826-836)
+#pragma unroll
+    for (int b = 0; b < K; b++) {
+        cbd_eval_f<ETA1>(raw_y[b], x);
+        wave_ntt_f(x, L.xch, tw);
+#pragma unroll
+        for (int m = 0; m < 4; m++) x[m] = fred(x[m]);
+        stash_vhat_f(L.vhat[b], L.vgam[b], x, tw);
+    }
+    wave_lds_fence();
+    // u[a] = InverseNTT(sum_b A^T[a][b] o y-hat[b]) + e1[a]  ->  Compress_du, ByteEncode_du   (ml_kem.c:854-896)
+#pragma unroll
+    for (int a = 0; a < K; a++) {
+        uint2 a_cur[K];
+#pragma unroll
+        for (int b = 0; b < K; b++) a_cur[b] = a_next[b];
+        if (a + 1 < K) {
+#pragma unroll
+            for (int b = 0; b < K; b++) a_next[b] = load_poly_raw(my_A + ((a + 1) * K + b) * 256);   // prefetch the next row
+        }
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int b = 0; b < K; b++) {
+            float av[4];
+            poly_raw_to_f(a_cur[b], av);
+            basemul_acc_f(acc, av, L.vhat[b], L.vgam[b]);
+        }
+        wave_intt_f(acc, L.xch, tw);
+        float e[4];
+        cbd_eval_f<2>(raw_e1[a], e);
+#pragma unroll
+        for (int m = 0; m < 4; m++) acc[m] += e[m];
+        diff |= emit_compressed<DU, COMPARE>(L.cbuf, acc, COMPARE ? nullptr : my_c + a * 32 * DU, cu_ref[COMPARE ? a : 0]);
+    }
+    // v = InverseNTT(t-hat . y-hat) + e2 + Decompress_1(m)  ->  Compress_dv, ByteEncode_dv   (ml_kem.c:867-904)
+    {
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int b = 0; b < K; b++) {
+            float tv[4];
+            decode_regs<12, false>(L.cbuf, that[b], tv);   // raw 12-bit values (F3)
+            basemul_acc_f(acc, tv, L.vhat[b], L.vgam[b]);
+        }
+        wave_intt_f(acc, L.xch, tw);
+        float e[4];
+        cbd_eval_f<2>(raw_e2, e);
+#pragma unroll
+        for (int m = 0; m < 4; m++) acc[m] += e[m] + (((mb >> m) & 1u) ? 1665.0f : 0.0f);   // Decompress_1(1) = 1665
+        diff |= emit_compressed<DV, COMPARE>(L.cbuf, acc, COMPARE ? nullptr : my_c + K * 32 * DU, cv_ref);
+    }
+    if constexpr (COMPARE) {
+        const bool mismatch = __ballot(diff != 0) != 0;
+        if (l < 8) {
+            const uint32_t* src = reinterpret_cast<const uint32_t*>((mismatch ? Kbar : Kp) + item * 32);
+            reinterpret_cast<uint32_t*>(Kout + item * 32)[l] = src[l];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_decrypt — K-PKE.Decrypt (ml_kem.c:942-1023): m' = ByteEncode_1(Compress_1(v - InverseNTT(s-hat . NTT(u))))
+// ------------------------------------------------------------------------------------------------
+template <int K, int DU, int DV>
+__global__ void __launch_bounds__(WAVE * ARITH_WAVES, MLKEM_ARITH_MINWAVES)
+k_decrypt(size_t n, const uint8_t* __restrict__ dk, size_t dk_stride, const uint8_t* __restrict__ c, uint8_t* __restrict__ m_out) {
+    __shared__ ArithLds<1> lds_all[ARITH_WAVES];
+    const int wv = (int)(threadIdx.x >> 6), l = lane_id();
+    const size_t item = (size_t)blockIdx.x * ARITH_WAVES + wv;
+    if (item >= n) return;
+    ArithLds<1>& L = lds_all[wv];
+    constexpr unsigned CLEN = 32 * (DU * K + DV);
+    const uint8_t* my_c = c + item * CLEN;
+    const uint8_t* my_dk = dk + item * dk_stride;
+    // prologue loads: u (ml_kem.c:978-987), s-hat (:996-998), v (:990-993)
+    CodecRegs<DU> cu[K];
+    CodecRegs<12> shat[K];
+    CodecRegs<DV> cv;
+#pragma unroll
+    for (int b = 0; b < K; b++) codec_fetch<DU>(my_c + b * 32 * DU, cu[b]);
+#pragma unroll
+    for (int b = 0; b < K; b++) codec_fetch<12>(my_dk + 384 * b, shat[b]);
+    codec_fetch<DV>(my_c + K * 32 * DU, cv);
+    NttTwiddlesF tw;
+    load_twiddles_f(tw);
+    float acc[4] = {0.f, 0.f, 0.f, 0.f}, x[4];
+#pragma unroll
+    for (int b = 0; b < K; b++) {
+        decode_regs<DU, true>(L.cbuf, cu[b], x);
+        wave_ntt_f(x, L.xch, tw);
+#pragma unroll
+        for (int m = 0; m < 4; m++) x[m] = fred(x[m]);
+        stash_vhat_f(L.vhat[0], L.vgam[0], x, tw);
+        wave_lds_fence();
+        float sv[4];
+        decode_regs<12, false>(L.cbuf, shat[b], sv);
+        basemul_acc_f(acc, sv, L.vhat[0], L.vgam[0]);
+        wave_lds_fence();
+    }
+    wave_intt_f(acc, L.xch, tw);
+    float v[4];
+    decode_regs<DV, true>(L.cbuf, cv, v);
+    unsigned bits = 0;
+#pragma unroll
+    for (int m = 0; m < 4; m++) bits |= compress_d<1>((unsigned)fcanon(v[m] - acc[m])) << m;   // ml_kem.c:1003-1011
+    // ByteEncode_1: lane l owns nibble l of the 32-byte message
+    const unsigned other = (unsigned)__shfl_xor((int)bits, 1);
+    if ((l & 1) == 0) m_out[item * 32 + (l >> 1)] = (uint8_t)(bits | (other << 4));
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_keygen — K-PKE.KeyGen after G and sampling (ml_kem.c:696-756) + the plain copies of KeyGen_internal
+// (ml_kem.c:1054-1062): ek = Enc12(t-hat) || rho ; dk = Enc12(s-hat) || ek || [H(ek)] || [z]
+// ------------------------------------------------------------------------------------------------
+template <int K, int ETA1>
+__global__ void __launch_bounds__(WAVE * ARITH_WAVES, MLKEM_ARITH_MINWAVES)
+k_keygen(size_t n, const uint16_t* __restrict__ A, const uint8_t* __restrict__ prf, const uint8_t* __restrict__ rho,
+         uint8_t* __restrict__ ek, uint8_t* __restrict__ dk) {
+    __shared__ ArithLds<K> lds_all[ARITH_WAVES];
+    const int wv = (int)(threadIdx.x >> 6), l = lane_id();
+    const size_t item = (size_t)blockIdx.x * ARITH_WAVES + wv;
+    if (item >= n) return;
+    ArithLds<K>& L = lds_all[wv];
+    constexpr unsigned PS = (ETA1 == 3) ? 192 : 128, EK = 384 * K + 32, DK = 768 * K + 96;
+    const uint8_t* my_prf = prf + item * (size_t)(2 * K * PS);
+    const uint16_t* my_A = A + item * (size_t)(K * K * 256);
+    uint8_t* my_ek = ek + item * EK;
+    uint8_t* my_dk = dk + item * DK;
+    uint32_t raw_s[K], raw_e[K];
+#pragma unroll
+    for (int b = 0; b < K; b++) raw_s[b] = cbd_load<ETA1>(my_prf + b * PS);
+    uint2 a_next[K];
+#pragma unroll
+    for (int b = 0; b < K; b++) a_next[b] = load_poly_raw(my_A + b * 256);
+#pragma unroll
+    for (int a = 0; a < K; a++) raw_e[a] = cbd_load<ETA1>(my_prf + (K + a) * PS);
+    const uint32_t rho_w = reinterpret_cast<const uint32_t*>(rho + item * 32)[l & 7];
+    NttTwiddlesF tw;
+    load_twiddles_f(tw);
+    float x[4];
+    // s-hat (ml_kem.c:696-706), dk_pke = ByteEncode_12(s-hat) (ml_kem.c:750-756)
+#pragma unroll
+    for (int b = 0; b < K; b++) {
+        cbd_eval_f<ETA1>(raw_s[b], x);
+        wave_ntt_f(x, L.xch, tw);
+#pragma unroll
+        for (int m = 0; m < 4; m++) x[m] = fred(x[m]);
+        stash_vhat_f(L.vhat[b], L.vgam[b], x, tw);
+        emit_encode12(L.cbuf, x, my_dk + 384 * b, nullptr);
+    }
+    wave_lds_fence();
+    // t-hat[a] = sum_b A[a][b] o s-hat[b] + e-hat[a] (ml_kem.c:710-727), ek = ByteEncode_12(t-hat) || rho
+#pragma unroll
+    for (int a = 0; a < K; a++) {
+        uint2 a_cur[K];
+#pragma unroll
+        for (int b = 0; b < K; b++) a_cur[b] = a_next[b];
+        if (a + 1 < K) {
+#pragma unroll
+            for (int b = 0; b < K; b++) a_next[b] = load_poly_raw(my_A + ((a + 1) * K + b) * 256);
+        }
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int b = 0; b < K; b++) {
+            float av[4];
+            poly_raw_to_f(a_cur[b], av);
+            basemul_acc_f(acc, av, L.vhat[b], L.vgam[b]);
+        }
+        float e[4];
+        cbd_eval_f<ETA1>(raw_e[a], e);
+        wave_ntt_f(e, L.xch, tw);
+#pragma unroll
+        for (int m = 0; m < 4; m++) acc[m] += e[m];   // <= 1665 + 6660
+        emit_encode12(L.cbuf, acc, my_ek + 384 * a, my_dk + 384 * K + 384 * a);
+    }
+    if (l < 8) {
+        reinterpret_cast<uint32_t*>(my_ek + 384 * K)[l] = rho_w;
+        reinterpret_cast<uint32_t*>(my_dk + 768 * K)[l] = rho_w;
+    }
+}
+
+// ================================================================================================
+// stand-alone primitives (C-ABI: mlkem_ntt / mlkem_intt / mlkem_multiply_ntts / mlkem_sample_cbd)
+// ================================================================================================
+// NTT / InverseNTT over n polynomials (ml_kem.c:287 / :336), uint16 in/out, canonical output.  One polynomial per
+// wave and iteration, grid-stride with the next polynomial requested before the current one is transformed;
+// inputs are taken mod 2^12 like the reference's 12-bit fields.
+template <bool INVERSE>
+__global__ void __launch_bounds__(WAVE * ARITH_WAVES) k_ntt_batch(size_t n, const uint16_t* __restrict__ in, uint16_t* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) float xch_all[ARITH_WAVES][256];
+    const int wv = (int)(threadIdx.x >> 6);
+    NttTwiddlesF tw;
+    load_twiddles_f(tw);
+    const size_t stride = (size_t)gridDim.x * ARITH_WAVES;
+    size_t p = (size_t)blockIdx.x * ARITH_WAVES + wv;
+    if (p >= n) return;
+    uint2 v_next = load_poly_raw(in + p * 256);
+    for (; p < n; p += stride) {
+        const uint2 v = v_next;
+        if (p + stride < n) v_next = load_poly_raw(in + (p + stride) * 256);
+        float x[4];
+        x[0] = (float)(v.x & 0xFFFu); x[1] = (float)((v.x >> 16) & 0xFFFu);
+        x[2] = (float)(v.y & 0xFFFu); x[3] = (float)((v.y >> 16) & 0xFFFu);
+        if constexpr (INVERSE) {
+#pragma unroll
+            for (int m = 0; m < 4; m++) x[m] = fred(x[m]);
+            wave_intt_f(x, xch_all[wv], tw);
+        } else {
+            wave_ntt_f(x, xch_all[wv], tw);
+        }
+        int o[4];
+#pragma unroll
+        for (int m = 0; m < 4; m++) o[m] = fcanon(x[m]);
+        store_poly_nat(out + p * 256, o);
+    }
+}
+
+// MultiplyNTTs (ml_kem.c:415-442): h = a o b, one polynomial pair per wave; inputs may be any 12-bit value
+__global__ void __launch_bounds__(WAVE * ARITH_WAVES) k_basemul_batch(size_t n, const uint16_t* __restrict__ a, const uint16_t* __restrict__ b,
+                                                                      uint16_t* __restrict__ h) {
+    __shared__ __attribute__((aligned(16))) float vh_all[ARITH_WAVES][256];
+    __shared__ __attribute__((aligned(16))) float vg_all[ARITH_WAVES][128];
+    const int wv = (int)(threadIdx.x >> 6);
+    NttTwiddlesF tw;
+    load_twiddles_f(tw);
+    const size_t stride = (size_t)gridDim.x * ARITH_WAVES;
+    for (size_t p = (size_t)blockIdx.x * ARITH_WAVES + wv; p < n; p += stride) {
+        float av[4], bv[4], acc[4] = {0.f, 0.f, 0.f, 0.f};
+        load_poly_nat_f12(a + p * 256, av);
+        load_poly_nat_f12(b + p * 256, bv);
+#pragma unroll
+        for (int m = 0; m < 4; m++) bv[m] = fred(bv[m]);
+        stash_vhat_f(vh_all[wv], vg_all[wv], bv, tw);
+        wave_lds_fence();
+        basemul_acc_f(acc, av, vh_all[wv], vg_all[wv]);
+        wave_lds_fence();
+        int o[4];
+#pragma unroll
+        for (int m = 0; m < 4; m++) o[m] = fcanon(acc[m]);
+        store_poly_nat(h + p * 256, o);
+    }
+}
+
+// SamplePolyCBD (ml_kem.c:253-275): bytes [n][64*eta] -> canonical uint16 polynomials
+template <int ETA>
+__global__ void __launch_bounds__(WAVE * ARITH_WAVES) k_cbd_batch(size_t n, const uint8_t* __restrict__ bytes, uint16_t* __restrict__ out) {
+    const int wv = (int)(threadIdx.x >> 6);
+    const size_t stride = (size_t)gridDim.x * ARITH_WAVES;
+    for (size_t p = (size_t)blockIdx.x * ARITH_WAVES + wv; p < n; p += stride) {
+        int x[4];
+        cbd_nat<ETA>(bytes + p * 64 * ETA, x);
+#pragma unroll
+        for (int m = 0; m < 4; m++) x[m] += (x[m] >> 31) & KQ;
+        store_poly_nat(out + p * 256, x);
+    }
+}
+
+}   // namespace mlkem

@@ -3,11 +3,10 @@
 // Everything here is wave64-native:
 //   * Keccak-f[1600] is lane-sliced (one sponge per lane, 25 lanes x 2 x u32 VGPRs) and built from
 //     v_bitop3_b32 (3-input LUT: xor3 for theta, a^(~b&c) for chi) and v_alignbit_b32 (64-bit rotates).
-//   * NTT / InverseNTT run one polynomial per wavefront, 4 coefficients per lane, radix-4 register
-//     stages with the three cross-lane re-layouts staged through wave-private LDS.
-//   * All modular arithmetic is exact integer work: signed Montgomery products (R = 2^16) with lazy
-//     reduction, Barrett reductions for canonicalisation; results are canonical in [0, q) and hence
-//     bit-identical to the reference's `% Q` arithmetic (ml_kem.c:287-442).
+//   * NTT / InverseNTT (mlkem_fntt.hpp) run one polynomial per wavefront, 4 coefficients per lane, radix-4
+//     register stages with the three cross-lane re-layouts staged through wave-private LDS; the mod-3329
+//     arithmetic is exact (integers < 2^24 on the fp32 pipe, Barrett reduction by reciprocal multiply), so
+//     results are canonical in [0, q) and bit-identical to the reference's `% Q` arithmetic (ml_kem.c:287-442).
 //
 // Reference behaviour that is reproduced on purpose: PRF and J are SHAKE128
 // (ml_kem.c:508, :546), ByteDecode_12 does not reduce mod q (ml_kem.c:170).
@@ -20,13 +19,10 @@
 namespace mlkem {
 
 constexpr int KQ = 3329;
-constexpr int QINV16 = 62209;   // q^-1 mod 2^16
-constexpr int MONT = 2285;      // 2^16 mod q
-constexpr int MONT2 = 1353;     // 2^32 mod q
 constexpr int INV128 = 3303;    // 128^-1 mod q (ml_kem.c:378-381)
 
 // ----------------------------------------------------------------------------------------------
-// compile-time tables: zeta_i = 17^BitRev7(i) (ml_kem.c:300-307), stored in Montgomery form, centred
+// compile-time helpers for the twiddle tables: zeta_i = 17^BitRev7(i) (ml_kem.c:300-307)
 // ----------------------------------------------------------------------------------------------
 constexpr int cx_bitrev7(int r) {
     int o = 0;
@@ -39,40 +35,9 @@ constexpr int cx_pow17(int e) {
     return r;
 }
 constexpr int cx_centered(int x) { return x > KQ / 2 ? x - KQ : x; }
-struct ZetaTable {
-    int16_t z[128];
-    constexpr ZetaTable() : z{} {
-        for (int i = 0; i < 128; i++) z[i] = (int16_t)cx_centered((cx_pow17(cx_bitrev7(i)) * MONT) % KQ);
-    }
-};
-__device__ const ZetaTable ZETA_MONT = ZetaTable();   // zeta_i * 2^16 mod q, centred
-
 // ----------------------------------------------------------------------------------------------
-// modular arithmetic
+// integer helpers for Compress / Decompress
 // ----------------------------------------------------------------------------------------------
-// Montgomery reduction: t * 2^-16 mod q, result in (-q, q) for |t| < 2^31 - 2^15 q.
-__device__ __forceinline__ int mont_reduce(int t) {
-    int m = (int)(int16_t)(__umul24((unsigned)t, (unsigned)QINV16));   // low 16 bits, sign-extended
-    return (t - __mul24(m, KQ)) >> 16;
-}
-__device__ __forceinline__ int fqmul(int a, int b) { return mont_reduce(__mul24(a, b)); }
-
-// Barrett for |x| < 2^15: centred representative in [-(q-1)/2, (q-1)/2]
-__device__ __forceinline__ int barrett16(int x) {
-    int t = (x * 20159 + (1 << 25)) >> 26;
-    return x - t * KQ;
-}
-// cheap Barrett for |x| < 2^21: result in [-q, 2q)
-__device__ __forceinline__ int red21(int x) {
-    int t = (x * 315) >> 20;
-    return x - t * KQ;
-}
-// canonical representative in [0, q) of |x| < 2^15
-__device__ __forceinline__ int canon16(int x) {
-    int r = barrett16(x);
-    return r + ((r >> 31) & KQ);
-}
-
 // floor(num / q) for 0 <= num < 2^23 (exact: see DESIGN.md "division by q")
 __device__ __forceinline__ unsigned div_q(unsigned num) {
     return (unsigned)(((uint64_t)num * 10321340ull) >> 35);
@@ -192,143 +157,29 @@ __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 __device__ __forceinline__ void wave_lds_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); }
 
 // ----------------------------------------------------------------------------------------------
-// One-polynomial-per-wave NTT.  Lane l holds 4 coefficients x[0..3]; layouts:
-//   NAT : c[4l + m]                      (contiguous; = basemul pair layout and HBM layout)
+// Coefficient layouts of the one-polynomial-per-wave NTT (mlkem_fntt.hpp).  Lane l holds 4 coefficients x[0..3]:
+//   NAT : c[4l + m]                      (contiguous; = basemul pair layout and HBM layout; layer len = 2)
 //   LA  : c[l + 64 m]                    (layers len = 128, 64 in registers)
 //   LB  : c[64 (l/16) + (l%16) + 16 m]   (len = 32, 16)
 //   LC  : c[16 (l/4)  + (l%4)  +  4 m]   (len = 8, 4)
-//   NAT again for len = 2.
-// `xch` is a wave-private LDS buffer of 256 int16.
 // ----------------------------------------------------------------------------------------------
-struct NttTwiddles {   // per-lane Montgomery-form twiddles, loaded once per kernel
-    int fB0, fB1, fB2;   // forward stage B: zeta[4+blk], zeta[8+2blk], zeta[9+2blk]
-    int fC0, fC1, fC2;   // forward stage C: zeta[16+b16], zeta[32+2b16], zeta[33+2b16]
-    int fD;              // forward stage D: zeta[64+l]  (also gamma for basemul pair 2l; pair 2l+1 uses -fD)
-    int iD;              // inverse len=2 : zeta[127-l]
-    int iC0, iC1, iC2;   // inverse len=4 : zeta[63-2b16], zeta[62-2b16]; len=8: zeta[31-b16]
-    int iB0, iB1, iB2;   // inverse len=16: zeta[15-2blk], zeta[14-2blk]; len=32: zeta[7-blk]
-};
-__device__ __forceinline__ void load_twiddles(NttTwiddles& t) {
-    const int l = lane_id(), blk = l >> 4, b16 = l >> 2;
-    const int16_t* z = ZETA_MONT.z;
-    t.fB0 = z[4 + blk]; t.fB1 = z[8 + 2 * blk]; t.fB2 = z[9 + 2 * blk];
-    t.fC0 = z[16 + b16]; t.fC1 = z[32 + 2 * b16]; t.fC2 = z[33 + 2 * b16];
-    t.fD = z[64 + l];
-    t.iD = z[127 - l];
-    t.iC0 = z[63 - 2 * b16]; t.iC1 = z[62 - 2 * b16]; t.iC2 = z[31 - b16];
-    t.iB0 = z[15 - 2 * blk]; t.iB1 = z[14 - 2 * blk]; t.iB2 = z[7 - blk];
+// The exchange buffer is addressed through an XOR swizzle so that all four access patterns are bank-conflict free
+// for ds_read_b32 / ds_write_b32 (32 banks, two 32-lane groups): index bits 3..2 ^= bits 6..5, bit 4 ^= bit 6.
+// Bits 1..0 are untouched, so a lane's 4 consecutive NAT coefficients stay one aligned 16-byte slot.
+#ifndef MLKEM_XCH_SWIZZLE
+#define MLKEM_XCH_SWIZZLE 1
+#endif
+__device__ __forceinline__ int xch_swz(int i) {
+#if MLKEM_XCH_SWIZZLE
+    return i ^ (((i >> 5) & 3) << 2) ^ (((i >> 6) & 1) << 4);
+#else
+    return i;
+#endif
 }
-// wave-uniform twiddles (compile-time)
-constexpr int Z1 = cx_centered((cx_pow17(cx_bitrev7(1)) * MONT) % KQ);
-constexpr int Z2 = cx_centered((cx_pow17(cx_bitrev7(2)) * MONT) % KQ);
-constexpr int Z3 = cx_centered((cx_pow17(cx_bitrev7(3)) * MONT) % KQ);
-
-// Cooley-Tukey butterfly (ml_kem.c:311-324), lazy: outputs grow by < q per layer
-__device__ __forceinline__ void ct_bfly(int& a, int& b, int zeta) {
-    int t = fqmul(zeta, b);
-    b = a - t;
-    a = a + t;
-}
-// Gentleman-Sande butterfly (ml_kem.c:359-373), lazy
-__device__ __forceinline__ void gs_bfly(int& a, int& b, int zeta) {
-    int t = a;
-    a = t + b;
-    b = fqmul(zeta, b - t);
-}
-
-__device__ __forceinline__ int idx_LA(int l, int m) { return l + 64 * m; }
-__device__ __forceinline__ int idx_LB(int l, int m) { return 64 * (l >> 4) + (l & 15) + 16 * m; }
-__device__ __forceinline__ int idx_LC(int l, int m) { return 16 * (l >> 2) + (l & 3) + 4 * m; }
-
-// write 4 strided coefficients / read 4 strided coefficients through the exchange buffer
-#define MLKEM_XCH_WRITE(IDX)                                          \
-    {                                                                 \
-        _Pragma("unroll") for (int m = 0; m < 4; m++) xch[IDX(l, m)] = (int16_t)x[m]; \
-    }
-#define MLKEM_XCH_READ(IDX)                                           \
-    {                                                                 \
-        _Pragma("unroll") for (int m = 0; m < 4; m++) x[m] = xch[IDX(l, m)]; \
-    }
-__device__ __forceinline__ void xch_write_nat(int16_t* xch, int l, const int (&x)[4]) {
-    uint2 v;
-    v.x = ((uint32_t)x[0] & 0xFFFFu) | ((uint32_t)x[1] << 16);
-    v.y = ((uint32_t)x[2] & 0xFFFFu) | ((uint32_t)x[3] << 16);
-    *reinterpret_cast<uint2*>(xch + 4 * l) = v;
-}
-__device__ __forceinline__ void xch_read_nat(const int16_t* xch, int l, int (&x)[4]) {
-    uint2 v = *reinterpret_cast<const uint2*>(xch + 4 * l);
-    x[0] = (int)(int16_t)(v.x & 0xFFFFu); x[1] = (int)v.x >> 16;
-    x[2] = (int)(int16_t)(v.y & 0xFFFFu); x[3] = (int)v.y >> 16;
-}
-
-// Forward NTT (ml_kem.c:287-329).  In: NAT layout, |x| < q.  Out: NAT layout, |x| < 8q (lazy).
-__device__ __forceinline__ void wave_ntt(int (&x)[4], int16_t* xch, const NttTwiddles& tw) {
-    const int l = lane_id();
-    xch_write_nat(xch, l, x);
-    wave_lds_fence();
-    MLKEM_XCH_READ(idx_LA)
-    ct_bfly(x[0], x[2], Z1); ct_bfly(x[1], x[3], Z1);          // len = 128
-    ct_bfly(x[0], x[1], Z2); ct_bfly(x[2], x[3], Z3);          // len = 64
-    wave_lds_fence();
-    MLKEM_XCH_WRITE(idx_LA)
-    wave_lds_fence();
-    MLKEM_XCH_READ(idx_LB)
-    ct_bfly(x[0], x[2], tw.fB0); ct_bfly(x[1], x[3], tw.fB0);  // len = 32
-    ct_bfly(x[0], x[1], tw.fB1); ct_bfly(x[2], x[3], tw.fB2);  // len = 16
-    wave_lds_fence();
-    MLKEM_XCH_WRITE(idx_LB)
-    wave_lds_fence();
-    MLKEM_XCH_READ(idx_LC)
-    ct_bfly(x[0], x[2], tw.fC0); ct_bfly(x[1], x[3], tw.fC0);  // len = 8
-    ct_bfly(x[0], x[1], tw.fC1); ct_bfly(x[2], x[3], tw.fC2);  // len = 4
-    wave_lds_fence();
-    MLKEM_XCH_WRITE(idx_LC)
-    wave_lds_fence();
-    xch_read_nat(xch, l, x);
-    ct_bfly(x[0], x[2], tw.fD); ct_bfly(x[1], x[3], tw.fD);    // len = 2
-    wave_lds_fence();
-}
-
-// Inverse NTT (ml_kem.c:336-384).  In: NAT layout, |x| < 2^21.  Out: NAT layout, in (-q, q), multiplied by
-// `final_mont` through a Montgomery product (3303*R for plain inputs, 3303*R^2 for inputs carrying R^-1).
-__device__ __forceinline__ void wave_intt(int (&x)[4], int16_t* xch, const NttTwiddles& tw, int final_mont) {
-    const int l = lane_id();
-#pragma unroll
-    for (int m = 0; m < 4; m++) x[m] = red21(x[m]);              // < 2q
-    gs_bfly(x[0], x[2], tw.iD); gs_bfly(x[1], x[3], tw.iD);      // len = 2   -> < 4q
-    xch_write_nat(xch, l, x);
-    wave_lds_fence();
-    MLKEM_XCH_READ(idx_LC)
-#pragma unroll
-    for (int m = 0; m < 4; m++) x[m] = red21(x[m]);
-    gs_bfly(x[0], x[1], tw.iC0); gs_bfly(x[2], x[3], tw.iC1);    // len = 4
-    gs_bfly(x[0], x[2], tw.iC2); gs_bfly(x[1], x[3], tw.iC2);    // len = 8   -> < 8q
-    wave_lds_fence();
-    MLKEM_XCH_WRITE(idx_LC)
-    wave_lds_fence();
-    MLKEM_XCH_READ(idx_LB)
-#pragma unroll
-    for (int m = 0; m < 4; m++) x[m] = red21(x[m]);
-    gs_bfly(x[0], x[1], tw.iB0); gs_bfly(x[2], x[3], tw.iB1);    // len = 16
-    gs_bfly(x[0], x[2], tw.iB2); gs_bfly(x[1], x[3], tw.iB2);    // len = 32
-    wave_lds_fence();
-    MLKEM_XCH_WRITE(idx_LB)
-    wave_lds_fence();
-    MLKEM_XCH_READ(idx_LA)
-#pragma unroll
-    for (int m = 0; m < 4; m++) x[m] = red21(x[m]);
-    gs_bfly(x[0], x[1], Z3); gs_bfly(x[2], x[3], Z2);            // len = 64
-    gs_bfly(x[0], x[2], Z1); gs_bfly(x[1], x[3], Z1);            // len = 128
-#pragma unroll
-    for (int m = 0; m < 4; m++) x[m] = fqmul(x[m], final_mont);  // x 128^-1 (ml_kem.c:378-381)
-    wave_lds_fence();
-    MLKEM_XCH_WRITE(idx_LA)
-    wave_lds_fence();
-    xch_read_nat(xch, l, x);
-    wave_lds_fence();
-}
-constexpr int INTT_FINAL_PLAIN = cx_centered((INV128 * MONT) % KQ);                 // 3303 * R
-constexpr int INTT_FINAL_DEMONT = cx_centered((((INV128 * MONT) % KQ) * MONT) % KQ); // 3303 * R^2
+__device__ __forceinline__ int idx_NAT(int l) { return xch_swz(4 * l); }
+__device__ __forceinline__ int idx_LA(int l, int m) { return xch_swz(l + 64 * m); }
+__device__ __forceinline__ int idx_LB(int l, int m) { return xch_swz(64 * (l >> 4) + (l & 15) + 16 * m); }
+__device__ __forceinline__ int idx_LC(int l, int m) { return xch_swz(16 * (l >> 2) + (l & 3) + 4 * m); }
 
 // ----------------------------------------------------------------------------------------------
 // bit-packed codecs (ml_kem.c:125-177) through a wave-private LDS byte buffer.

@@ -1,0 +1,207 @@
+// mlkem_fntt.hpp — one-polynomial-per-wave NTT / InverseNTT / base-case multiply with EXACT arithmetic on the
+// fp32 pipe (ml_kem.c:287-442).
+//
+// Why fp32: on gfx950 every integer multiply (v_mul_*_i24/u24, v_mul_lo_u32, v_mad_*24), shift and bit-field op
+// issues at ~0.55x the rate of v_fma_f32 / v_mul_f32 / v_add_f32 (tools/valu_ubench2.hip, profiles/r01_valu_ubench.txt).
+// All values are integers of magnitude < 2^24, for which fp32 add / mul / fma are exact, so the results are
+// bit-identical to the reference's `% Q` arithmetic:
+//   product  p = zeta * b           exact while |p| <= 2^24  (|zeta| <= 1664 centred, |b| <= 10082)
+//   Barrett  k = rint(p / q)        via  k = fma(p, 1/q, 1.5*2^23) - 1.5*2^23   (round-to-nearest integer)
+//            r = fma(k, -q, p)      exact, |r| <= 1665
+// i.e. the reduction IS Barrett's (multiply by a precomputed reciprocal, round, subtract), evaluated in fp32.
+// Lazy bounds are tracked in the comments; `fred` is applied exactly where a bound would exceed 10082 (= 2^24/1664).
+#pragma once
+#include "mlkem_device.hpp"
+
+namespace mlkem {
+
+constexpr float F_Q = 3329.0f;
+constexpr float F_INVQ = 1.0f / 3329.0f;
+constexpr float F_MAGIC = 12582912.0f;   // 1.5 * 2^23: adding and subtracting rounds to the nearest integer
+
+// centred representative of x mod q, |result| <= 1665, for integer |x| <= 2^24
+__device__ __forceinline__ float fred(float x) {
+    const float k = __builtin_fmaf(x, F_INVQ, F_MAGIC) - F_MAGIC;
+    return __builtin_fmaf(k, -F_Q, x);
+}
+// zeta * b mod q (centred), |zeta * b| <= 2^24
+__device__ __forceinline__ float fmulmod(float zeta, float b) { return fred(zeta * b); }
+// canonical representative in [0, q) as an integer, for |x| <= 2^24
+__device__ __forceinline__ int fcanon(float x) {
+    float r = fred(x);
+    r = r < 0.0f ? r + F_Q : r;
+    return (int)r;
+}
+
+struct ZetaTableF {
+    float z[128];
+    constexpr ZetaTableF() : z{} {
+        for (int i = 0; i < 128; i++) z[i] = (float)cx_centered(cx_pow17(cx_bitrev7(i)));
+    }
+};
+__device__ const ZetaTableF ZETA_F = ZetaTableF();   // zeta_i = 17^BitRev7(i) mod q, centred (ml_kem.c:300-307)
+
+struct NttTwiddlesF {
+    float fB0, fB1, fB2, fC0, fC1, fC2, fD;   // forward: see NttTwiddles in mlkem_device.hpp for the index map
+    float iD, iC0, iC1, iC2, iB0, iB1, iB2;   // inverse
+};
+__device__ __forceinline__ void load_twiddles_f(NttTwiddlesF& t) {
+    const int l = lane_id(), blk = l >> 4, b16 = l >> 2;
+    const float* z = ZETA_F.z;
+    t.fB0 = z[4 + blk]; t.fB1 = z[8 + 2 * blk]; t.fB2 = z[9 + 2 * blk];
+    t.fC0 = z[16 + b16]; t.fC1 = z[32 + 2 * b16]; t.fC2 = z[33 + 2 * b16];
+    t.fD = z[64 + l];
+    t.iD = z[127 - l];
+    t.iC0 = z[63 - 2 * b16]; t.iC1 = z[62 - 2 * b16]; t.iC2 = z[31 - b16];
+    t.iB0 = z[15 - 2 * blk]; t.iB1 = z[14 - 2 * blk]; t.iB2 = z[7 - blk];
+}
+constexpr float FZ1 = (float)cx_centered(cx_pow17(cx_bitrev7(1)));
+constexpr float FZ2 = (float)cx_centered(cx_pow17(cx_bitrev7(2)));
+constexpr float FZ3 = (float)cx_centered(cx_pow17(cx_bitrev7(3)));
+constexpr float F_INV128 = (float)(INV128 - KQ);   // 128^-1 = 3303 = -26 mod q (ml_kem.c:378-381)
+
+// Cooley-Tukey (ml_kem.c:311-324): a' = a + zeta b, b' = a - zeta b ; bounds grow by 1665 per layer
+__device__ __forceinline__ void ct_bfly_f(float& a, float& b, float zeta) {
+    const float t = fmulmod(zeta, b);
+    b = a - t;
+    a = a + t;
+}
+// Gentleman-Sande (ml_kem.c:359-373): a' = a + b, b' = zeta (b - a)
+__device__ __forceinline__ void gs_bfly_f(float& a, float& b, float zeta) {
+    const float t = a;
+    a = t + b;
+    b = fmulmod(zeta, b - t);
+}
+
+#define MLKEM_FX_WRITE(IDX)                                                       \
+    {                                                                             \
+        _Pragma("unroll") for (int m = 0; m < 4; m++) xch[IDX(l, m)] = x[m];      \
+    }
+#define MLKEM_FX_READ(IDX)                                                        \
+    {                                                                             \
+        _Pragma("unroll") for (int m = 0; m < 4; m++) x[m] = xch[IDX(l, m)];      \
+    }
+// 4 consecutive coefficients of lane l as one 16-byte access: `slot` = 4l (linear buffers) or idx_NAT(l) (exchange buffer)
+__device__ __forceinline__ void fx_write4(float* buf, int slot, const float (&x)[4]) {
+    float4 v;
+    v.x = x[0]; v.y = x[1]; v.z = x[2]; v.w = x[3];
+    *reinterpret_cast<float4*>(buf + slot) = v;
+}
+__device__ __forceinline__ void fx_read4(const float* buf, int slot, float (&x)[4]) {
+    const float4 v = *reinterpret_cast<const float4*>(buf + slot);
+    x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w;
+}
+
+// Forward NTT (ml_kem.c:287-329).  In: NAT layout, |x| <= 3328.  Out: NAT layout, |x| <= 6663 (lazy).
+// `xch` = 256 floats of wave-private LDS.
+// wave_ntt_la_f takes the input already in LA layout (x[m] = c[l + 64 m]) and skips the first exchange.
+__device__ __forceinline__ void wave_ntt_la_f(float (&x)[4], float* xch, const NttTwiddlesF& tw);
+__device__ __forceinline__ void wave_ntt_f(float (&x)[4], float* xch, const NttTwiddlesF& tw) {
+    const int l = lane_id();
+    fx_write4(xch, idx_NAT(l), x);
+    wave_lds_fence();
+    MLKEM_FX_READ(idx_LA)
+    wave_lds_fence();
+    wave_ntt_la_f(x, xch, tw);
+}
+__device__ __forceinline__ void wave_ntt_la_f(float (&x)[4], float* xch, const NttTwiddlesF& tw) {
+    const int l = lane_id();
+    ct_bfly_f(x[0], x[2], FZ1); ct_bfly_f(x[1], x[3], FZ1);          // len 128 : <= 3328 + 1665
+    ct_bfly_f(x[0], x[1], FZ2); ct_bfly_f(x[2], x[3], FZ3);          // len 64  : <= 3328 + 2*1665
+    wave_lds_fence();
+    MLKEM_FX_WRITE(idx_LA)
+    wave_lds_fence();
+    MLKEM_FX_READ(idx_LB)
+    ct_bfly_f(x[0], x[2], tw.fB0); ct_bfly_f(x[1], x[3], tw.fB0);    // len 32
+    ct_bfly_f(x[0], x[1], tw.fB1); ct_bfly_f(x[2], x[3], tw.fB2);    // len 16  : <= 3328 + 4*1665 = 9988 (< 10082)
+#pragma unroll
+    for (int m = 0; m < 4; m++) x[m] = fred(x[m]);                    // <= 1665
+    wave_lds_fence();
+    MLKEM_FX_WRITE(idx_LB)
+    wave_lds_fence();
+    MLKEM_FX_READ(idx_LC)
+    ct_bfly_f(x[0], x[2], tw.fC0); ct_bfly_f(x[1], x[3], tw.fC0);    // len 8
+    ct_bfly_f(x[0], x[1], tw.fC1); ct_bfly_f(x[2], x[3], tw.fC2);    // len 4   : <= 1665 + 2*1665
+    wave_lds_fence();
+    MLKEM_FX_WRITE(idx_LC)
+    wave_lds_fence();
+    fx_read4(xch, idx_NAT(l), x);
+    ct_bfly_f(x[0], x[2], tw.fD); ct_bfly_f(x[1], x[3], tw.fD);      // len 2   : <= 6660
+    wave_lds_fence();
+}
+
+// Inverse NTT (ml_kem.c:336-384) including the final multiplication by 128^-1.
+// In: NAT layout, |x| <= 2520.  Out: NAT layout, |x| <= 1665 (centred).
+// Two lazy Gentleman-Sande layers per register stage need inputs <= 2520 (4 * 2520 <= 10082); after a stage the
+// two "sum path" values (x0 <= 4B, x1 <= 2B) are reduced before the exchange.
+__device__ __forceinline__ void wave_intt_f(float (&x)[4], float* xch, const NttTwiddlesF& tw) {
+    const int l = lane_id();
+    gs_bfly_f(x[0], x[2], tw.iD); gs_bfly_f(x[1], x[3], tw.iD);      // len 2 : sums <= 5040, products <= 1665
+    x[0] = fred(x[0]); x[1] = fred(x[1]);
+    fx_write4(xch, idx_NAT(l), x);
+    wave_lds_fence();
+    MLKEM_FX_READ(idx_LC)
+    gs_bfly_f(x[0], x[1], tw.iC0); gs_bfly_f(x[2], x[3], tw.iC1);    // len 4
+    gs_bfly_f(x[0], x[2], tw.iC2); gs_bfly_f(x[1], x[3], tw.iC2);    // len 8 : x0 <= 6660, x1 <= 3330, x2, x3 <= 1665
+    x[0] = fred(x[0]); x[1] = fred(x[1]);
+    wave_lds_fence();
+    MLKEM_FX_WRITE(idx_LC)
+    wave_lds_fence();
+    MLKEM_FX_READ(idx_LB)
+    gs_bfly_f(x[0], x[1], tw.iB0); gs_bfly_f(x[2], x[3], tw.iB1);    // len 16
+    gs_bfly_f(x[0], x[2], tw.iB2); gs_bfly_f(x[1], x[3], tw.iB2);    // len 32
+    x[0] = fred(x[0]); x[1] = fred(x[1]);
+    wave_lds_fence();
+    MLKEM_FX_WRITE(idx_LB)
+    wave_lds_fence();
+    MLKEM_FX_READ(idx_LA)
+    gs_bfly_f(x[0], x[1], FZ3); gs_bfly_f(x[2], x[3], FZ2);          // len 64
+    gs_bfly_f(x[0], x[2], FZ1); gs_bfly_f(x[1], x[3], FZ1);          // len 128 : <= 6660
+#pragma unroll
+    for (int m = 0; m < 4; m++) x[m] = fmulmod(F_INV128, x[m]);       // x 128^-1 : |-26 * 6660| << 2^24
+    wave_lds_fence();
+    MLKEM_FX_WRITE(idx_LA)
+    wave_lds_fence();
+    fx_read4(xch, idx_NAT(l), x);
+    wave_lds_fence();
+}
+
+// ---- base-case multiply-accumulate (ml_kem.c:395-442, :618-638) ------------------------------------------------
+// An NTT-domain polynomial v (reduced, |v| <= 1665) is kept in LDS together with its odd coefficients times gamma
+// (gamma_{2l} = zeta_{64+l}, gamma_{2l+1} = -gamma_{2l}).
+__device__ __forceinline__ void stash_vhat_f(float* vh, float* vg, const float (&x)[4], const NttTwiddlesF& tw) {
+    const int l = lane_id();
+    fx_write4(vh, 4 * l, x);
+    float2 g;
+    g.x = fmulmod(tw.fD, x[1]);
+    g.y = fmulmod(-tw.fD, x[3]);
+    *reinterpret_cast<float2*>(vg + 2 * l) = g;
+}
+// acc = (acc + a o v) reduced : for 0 <= a <= 4095 (raw 12-bit, F3) and |v|, |acc| <= 1665 the exact sum is
+// <= 1665 + 2 * 4095 * 1665 < 2^24, so the fp32 evaluation is exact and one `fred` per coefficient suffices.
+__device__ __forceinline__ void basemul_acc_f(float (&acc)[4], const float (&a)[4], const float* vh, const float* vg) {
+    const int l = lane_id();
+    float y[4];
+    fx_read4(vh, 4 * l, y);
+    const float2 g = *reinterpret_cast<const float2*>(vg + 2 * l);
+    acc[0] = fred(__builtin_fmaf(a[1], g.x, __builtin_fmaf(a[0], y[0], acc[0])));
+    acc[1] = fred(__builtin_fmaf(a[1], y[0], __builtin_fmaf(a[0], y[1], acc[1])));
+    acc[2] = fred(__builtin_fmaf(a[3], g.y, __builtin_fmaf(a[2], y[2], acc[2])));
+    acc[3] = fred(__builtin_fmaf(a[3], y[2], __builtin_fmaf(a[2], y[3], acc[3])));
+}
+
+// uint16 polynomial in HBM (natural order) -> 4 floats per lane (values 0..65535 -> exact)
+__device__ __forceinline__ void load_poly_nat_f(const uint16_t* p, float (&x)[4]) {
+    const uint2 v = *reinterpret_cast<const uint2*>(p + 4 * lane_id());
+    x[0] = (float)(v.x & 0xFFFFu); x[1] = (float)(v.x >> 16);
+    x[2] = (float)(v.y & 0xFFFFu); x[3] = (float)(v.y >> 16);
+}
+
+// same, taking the inputs mod 2^12 like the reference's 12-bit `union integer` fields
+__device__ __forceinline__ void load_poly_nat_f12(const uint16_t* p, float (&x)[4]) {
+    const uint2 v = *reinterpret_cast<const uint2*>(p + 4 * lane_id());
+    x[0] = (float)(v.x & 0xFFFu); x[1] = (float)((v.x >> 16) & 0xFFFu);
+    x[2] = (float)(v.y & 0xFFFu); x[3] = (float)((v.y >> 16) & 0xFFFu);
+}
+
+}   // namespace mlkem

@@ -6,10 +6,8 @@
 //                 the packed per-item byte strings are read from HBM in coalesced runs
 //   k_sample      lane = one SHAKE128 sponge; role XOF -> SampleNTT rejection sampling (ml_kem.c:189) with
 //                 an LDS ring per lane flushed in aligned 128-byte chunks; role PRF -> raw PRF bytes (ml_kem.c:496)
-//   k_keygen / k_encrypt / k_decrypt
-//                 wave = one KEM instance: CBD, NTT, base-case multiply-accumulate, inverse NTT, compress,
-//                 ByteEncode/Decode, ciphertext compare + key select, all in registers/LDS
-//   k_*_batch     stand-alone primitives behind the C-ABI (NTT-only workload of BASELINE config 2, parity tests)
+//                 (its three-block fast path lives in mlkem_sampler.hpp)
+// The wave-per-instance polynomial kernels (k_keygen / k_encrypt / k_decrypt, stand-alone NTT) are in mlkem_arith.hpp.
 //
 // No kernel uses a workgroup barrier: every wave is independent, LDS is carved per wave.
 #pragma once
@@ -507,347 +505,6 @@ __global__ void __launch_bounds__(WAVE) k_sample(SampleArgs a) {
             }
 #undef MLKEM_OW
         }
-    }
-}
-
-// ================================================================================================
-// wave-per-instance polynomial arithmetic
-// ================================================================================================
-constexpr int ARITH_WAVES = 4;   // waves per workgroup (each fully independent)
-
-template <int K>
-struct ArithLds {
-    __attribute__((aligned(16))) int16_t xch[256];
-    __attribute__((aligned(16))) int16_t vhat[K][256];   // NTT-domain vector (y-hat or s-hat), centred
-    __attribute__((aligned(16))) int16_t vgam[K][128];   // odd coefficient times gamma (ml_kem.c:402-403), per pair
-    uint32_t cbuf[CODEC_BUF_WORDS];
-};
-
-// keep an NTT-domain polynomial (NAT layout, centred) and its gamma-premultiplied odd coefficients in LDS
-__device__ __forceinline__ void stash_vhat(int16_t* vh, int16_t* vg, const int (&x)[4], const NttTwiddles& tw) {
-    const int l = lane_id();
-    xch_write_nat(vh, l, x);
-    const int g0 = fqmul(x[1], tw.fD), g1 = fqmul(x[3], -tw.fD);
-    *reinterpret_cast<uint32_t*>(vg + 2 * l) = ((uint32_t)g0 & 0xFFFFu) | ((uint32_t)g1 << 16);
-}
-// acc += MultiplyNTTs(a, v) (ml_kem.c:395-442) for the lane's two coefficient pairs, products left unreduced
-__device__ __forceinline__ void basemul_acc(int (&acc)[4], const int (&a)[4], const int16_t* vh, const int16_t* vg) {
-    const int l = lane_id();
-    int y[4];
-    xch_read_nat(vh, l, y);
-    const uint32_t gw = *reinterpret_cast<const uint32_t*>(vg + 2 * l);
-    const int yg0 = (int)(int16_t)(gw & 0xFFFFu), yg1 = (int)gw >> 16;
-    acc[0] += __mul24(a[0], y[0]) + __mul24(a[1], yg0);
-    acc[1] += __mul24(a[0], y[1]) + __mul24(a[1], y[0]);
-    acc[2] += __mul24(a[2], y[2]) + __mul24(a[3], yg1);
-    acc[3] += __mul24(a[2], y[3]) + __mul24(a[3], y[2]);
-}
-// load the lane's 4 coefficients of a uint16 polynomial in HBM (8 bytes per lane, 512 B per wave)
-__device__ __forceinline__ void load_poly_nat(const uint16_t* p, int (&x)[4]) {
-    uint2 v = *reinterpret_cast<const uint2*>(p + 4 * lane_id());
-    x[0] = (int)(v.x & 0xFFFFu); x[1] = (int)(v.x >> 16);
-    x[2] = (int)(v.y & 0xFFFFu); x[3] = (int)(v.y >> 16);
-}
-__device__ __forceinline__ void store_poly_nat(uint16_t* p, const int (&x)[4]) {
-    uint2 v;
-    v.x = ((uint32_t)x[0] & 0xFFFFu) | ((uint32_t)x[1] << 16);
-    v.y = ((uint32_t)x[2] & 0xFFFFu) | ((uint32_t)x[3] << 16);
-    *reinterpret_cast<uint2*>(p + 4 * lane_id()) = v;
-}
-
-// Compress_D + ByteEncode_D of a canonical polynomial, then either store the bytes or compare with `ref`
-template <int D, bool COMPARE>
-__device__ __forceinline__ uint32_t emit_compressed(uint32_t* cbuf, const int (&x)[4], uint8_t* out, const uint8_t* ref) {
-    unsigned v[4];
-#pragma unroll
-    for (int m = 0; m < 4; m++) v[m] = compress_d<D>((unsigned)x[m]);
-    codec_zero<D>(cbuf);
-    wave_lds_fence();
-    codec_encode<D>(cbuf, v);
-    wave_lds_fence();
-    uint32_t diff = 0;
-    if constexpr (COMPARE) diff = codec_diff_bytes<D>(cbuf, ref);
-    else codec_store_bytes<D>(cbuf, out);
-    wave_lds_fence();
-    return diff;
-}
-// ByteEncode_12 of a canonical polynomial (ml_kem.c:736-756) to one or two destinations
-__device__ __forceinline__ void emit_encode12(uint32_t* cbuf, const int (&x)[4], uint8_t* out0, uint8_t* out1) {
-    unsigned v[4];
-#pragma unroll
-    for (int m = 0; m < 4; m++) v[m] = (unsigned)x[m];
-    codec_zero<12>(cbuf);
-    wave_lds_fence();
-    codec_encode<12>(cbuf, v);
-    wave_lds_fence();
-    codec_store_bytes<12>(cbuf, out0);
-    if (out1) codec_store_bytes<12>(cbuf, out1);
-    wave_lds_fence();
-}
-// ByteDecode_D (+ optional Decompress_D) of 32*D bytes in HBM into the lane's 4 coefficients
-template <int D, bool DECOMPRESS>
-__device__ __forceinline__ void fetch_decoded(uint32_t* cbuf, const uint8_t* src, int (&x)[4]) {
-    unsigned v[4];
-    codec_load_bytes<D>(cbuf, src);
-    wave_lds_fence();
-    codec_decode<D>(cbuf, v);
-    wave_lds_fence();
-#pragma unroll
-    for (int m = 0; m < 4; m++) {
-        if constexpr (DECOMPRESS) x[m] = (int)decompress_d<D>(v[m]);
-        else x[m] = (int)v[m];
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// k_encrypt — K-PKE.Encrypt (ml_kem.c:776-936) given A^T (k_sample, XOF role) and the PRF bytes (PRF role).
-//   COMPARE = false : write c                                   (Encaps_internal, ml_kem.c:1127)
-//   COMPARE = true  : compare c' with c, K = (c == c') ? K' : Kbar (Decaps_internal, ml_kem.c:1206-1215)
-// ------------------------------------------------------------------------------------------------
-template <int K, int ETA1, int DU, int DV, bool COMPARE>
-__global__ void __launch_bounds__(WAVE * ARITH_WAVES) k_encrypt(size_t n, const uint8_t* __restrict__ ek, size_t ek_stride,
-                                                                const uint8_t* __restrict__ msg, const uint16_t* __restrict__ A,
-                                                                const uint8_t* __restrict__ prf, uint8_t* __restrict__ c_out,
-                                                                const uint8_t* __restrict__ c_in, const uint8_t* __restrict__ Kp,
-                                                                const uint8_t* __restrict__ Kbar, uint8_t* __restrict__ Kout) {
-    __shared__ ArithLds<K> lds_all[ARITH_WAVES];
-    const int wv = (int)(threadIdx.x >> 6), l = lane_id();
-    const size_t item = (size_t)blockIdx.x * ARITH_WAVES + wv;
-    if (item >= n) return;
-    ArithLds<K>& L = lds_all[wv];
-    constexpr unsigned PS = (ETA1 == 3) ? 192 : 128, CLEN = 32 * (DU * K + DV);
-    NttTwiddles tw;
-    load_twiddles(tw);
-    const uint8_t* my_prf = prf + item * (size_t)((2 * K + 1) * PS);
-    const uint8_t* my_ek = ek + item * ek_stride;
-    const uint16_t* my_A = A + item * (size_t)(K * K * 256);
-    uint8_t* my_c = COMPARE ? nullptr : c_out + item * CLEN;
-    const uint8_t* my_cin = COMPARE ? c_in + item * CLEN : nullptr;
-    uint32_t diff = 0;
-    int x[4];
-    // y-hat = NTT(CBD_eta1(PRF(r, n)))  n = 0..K-1   (ml_kem.c:826-836)
-#pragma unroll
-    for (int b = 0; b < K; b++) {
-        cbd_nat<ETA1>(my_prf + b * PS, x);
-        wave_ntt(x, L.xch, tw);
-#pragma unroll
-        for (int m = 0; m < 4; m++) x[m] = barrett16(x[m]);
-        stash_vhat(L.vhat[b], L.vgam[b], x, tw);
-    }
-    wave_lds_fence();
-    // u[a] = InverseNTT(sum_b A^T[a][b] o y-hat[b]) + e1[a]  ->  Compress_du, ByteEncode_du   (ml_kem.c:854-896)
-#pragma unroll 1
-    for (int a = 0; a < K; a++) {
-        int acc[4] = {0, 0, 0, 0};
-#pragma unroll
-        for (int b = 0; b < K; b++) {
-            int av[4];
-            load_poly_nat(my_A + (a * K + b) * 256, av);
-            basemul_acc(acc, av, L.vhat[b], L.vgam[b]);
-        }
-#pragma unroll
-        for (int m = 0; m < 4; m++) x[m] = mont_reduce(acc[m]);
-        wave_intt(x, L.xch, tw, INTT_FINAL_DEMONT);
-        int e[4];
-        cbd_nat<2>(my_prf + (K + a) * PS, e);
-#pragma unroll
-        for (int m = 0; m < 4; m++) x[m] = canon16(x[m] + e[m]);
-        diff |= emit_compressed<DU, COMPARE>(L.cbuf, x, COMPARE ? nullptr : my_c + a * 32 * DU,
-                                             COMPARE ? my_cin + a * 32 * DU : nullptr);
-    }
-    // v = InverseNTT(t-hat . y-hat) + e2 + Decompress_1(m)  ->  Compress_dv, ByteEncode_dv   (ml_kem.c:867-904)
-    {
-        int acc[4] = {0, 0, 0, 0};
-#pragma unroll
-        for (int b = 0; b < K; b++) {
-            int tv[4];
-            fetch_decoded<12, false>(L.cbuf, my_ek + 384 * b, tv);   // raw 12-bit values, no mod q (F3)
-            basemul_acc(acc, tv, L.vhat[b], L.vgam[b]);
-        }
-#pragma unroll
-        for (int m = 0; m < 4; m++) x[m] = mont_reduce(acc[m]);
-        wave_intt(x, L.xch, tw, INTT_FINAL_DEMONT);
-        int e[4];
-        cbd_nat<2>(my_prf + (2 * K) * PS, e);
-        const unsigned mb = msg[item * 32 + (l >> 1)] >> (4 * (l & 1));   // the lane's 4 message bits
-#pragma unroll
-        for (int m = 0; m < 4; m++) x[m] = canon16(x[m] + e[m] + (int)(((mb >> m) & 1u) * 1665u));
-        diff |= emit_compressed<DV, COMPARE>(L.cbuf, x, COMPARE ? nullptr : my_c + K * 32 * DU,
-                                             COMPARE ? my_cin + K * 32 * DU : nullptr);
-    }
-    if constexpr (COMPARE) {
-        const bool mismatch = __ballot(diff != 0) != 0;
-        if (l < 8) {
-            const uint32_t* src = reinterpret_cast<const uint32_t*>((mismatch ? Kbar : Kp) + item * 32);
-            reinterpret_cast<uint32_t*>(Kout + item * 32)[l] = src[l];
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// k_decrypt — K-PKE.Decrypt (ml_kem.c:942-1023): m' = ByteEncode_1(Compress_1(v - InverseNTT(s-hat . NTT(u))))
-// ------------------------------------------------------------------------------------------------
-template <int K, int DU, int DV>
-__global__ void __launch_bounds__(WAVE * ARITH_WAVES) k_decrypt(size_t n, const uint8_t* __restrict__ dk, size_t dk_stride,
-                                                                const uint8_t* __restrict__ c, uint8_t* __restrict__ m_out) {
-    __shared__ ArithLds<1> lds_all[ARITH_WAVES];
-    const int wv = (int)(threadIdx.x >> 6), l = lane_id();
-    const size_t item = (size_t)blockIdx.x * ARITH_WAVES + wv;
-    if (item >= n) return;
-    ArithLds<1>& L = lds_all[wv];
-    constexpr unsigned CLEN = 32 * (DU * K + DV);
-    NttTwiddles tw;
-    load_twiddles(tw);
-    const uint8_t* my_c = c + item * CLEN;
-    const uint8_t* my_dk = dk + item * dk_stride;
-    int acc[4] = {0, 0, 0, 0}, x[4];
-#pragma unroll 1
-    for (int b = 0; b < K; b++) {
-        fetch_decoded<DU, true>(L.cbuf, my_c + b * 32 * DU, x);          // u[b] (ml_kem.c:978-987)
-        wave_ntt(x, L.xch, tw);
-#pragma unroll
-        for (int m = 0; m < 4; m++) x[m] = barrett16(x[m]);
-        stash_vhat(L.vhat[0], L.vgam[0], x, tw);
-        wave_lds_fence();
-        int sv[4];
-        fetch_decoded<12, false>(L.cbuf, my_dk + 384 * b, sv);            // s-hat[b] (ml_kem.c:996-998)
-        basemul_acc(acc, sv, L.vhat[0], L.vgam[0]);
-        wave_lds_fence();
-    }
-#pragma unroll
-    for (int m = 0; m < 4; m++) x[m] = mont_reduce(acc[m]);
-    wave_intt(x, L.xch, tw, INTT_FINAL_DEMONT);
-    int v[4];
-    fetch_decoded<DV, true>(L.cbuf, my_c + K * 32 * DU, v);              // v (ml_kem.c:990-993)
-    unsigned bits = 0;
-#pragma unroll
-    for (int m = 0; m < 4; m++) {
-        const int w = canon16(v[m] - x[m]);                              // ml_kem.c:1003
-        bits |= compress_d<1>((unsigned)w) << m;                         // ml_kem.c:1009-1011
-    }
-    // ByteEncode_1: lane l owns nibble l of the 32-byte message
-    const unsigned other = (unsigned)__shfl_xor((int)bits, 1);
-    if ((l & 1) == 0) m_out[item * 32 + (l >> 1)] = (uint8_t)(bits | (other << 4));
-}
-
-// ------------------------------------------------------------------------------------------------
-// k_keygen — K-PKE.KeyGen after G and sampling (ml_kem.c:696-756) + the parts of KeyGen_internal that are
-// plain copies (ml_kem.c:1054-1062): ek = Enc12(t-hat) || rho ; dk = Enc12(s-hat) || ek || [H(ek)] || [z]
-// ------------------------------------------------------------------------------------------------
-template <int K, int ETA1>
-__global__ void __launch_bounds__(WAVE * ARITH_WAVES) k_keygen(size_t n, const uint16_t* __restrict__ A, const uint8_t* __restrict__ prf,
-                                                               const uint8_t* __restrict__ rho, uint8_t* __restrict__ ek,
-                                                               uint8_t* __restrict__ dk) {
-    __shared__ ArithLds<K> lds_all[ARITH_WAVES];
-    const int wv = (int)(threadIdx.x >> 6), l = lane_id();
-    const size_t item = (size_t)blockIdx.x * ARITH_WAVES + wv;
-    if (item >= n) return;
-    ArithLds<K>& L = lds_all[wv];
-    constexpr unsigned PS = (ETA1 == 3) ? 192 : 128, EK = 384 * K + 32, DK = 768 * K + 96;
-    NttTwiddles tw;
-    load_twiddles(tw);
-    const uint8_t* my_prf = prf + item * (size_t)(2 * K * PS);
-    const uint16_t* my_A = A + item * (size_t)(K * K * 256);
-    uint8_t* my_ek = ek + item * EK;
-    uint8_t* my_dk = dk + item * DK;
-    int x[4];
-    // s-hat (ml_kem.c:696-706), dk_pke = ByteEncode_12(s-hat) (ml_kem.c:750-756)
-#pragma unroll 1
-    for (int b = 0; b < K; b++) {
-        cbd_nat<ETA1>(my_prf + b * PS, x);
-        wave_ntt(x, L.xch, tw);
-        int cx[4];
-#pragma unroll
-        for (int m = 0; m < 4; m++) { x[m] = barrett16(x[m]); cx[m] = x[m] + ((x[m] >> 31) & KQ); }
-        stash_vhat(L.vhat[b], L.vgam[b], x, tw);
-        emit_encode12(L.cbuf, cx, my_dk + 384 * b, nullptr);
-    }
-    wave_lds_fence();
-    // t-hat[a] = sum_b A[a][b] o s-hat[b] + e-hat[a] (ml_kem.c:710-727), ek = ByteEncode_12(t-hat) || rho
-#pragma unroll 1
-    for (int a = 0; a < K; a++) {
-        int acc[4] = {0, 0, 0, 0};
-#pragma unroll
-        for (int b = 0; b < K; b++) {
-            int av[4];
-            load_poly_nat(my_A + (a * K + b) * 256, av);
-            basemul_acc(acc, av, L.vhat[b], L.vgam[b]);
-        }
-        int e[4];
-        cbd_nat<ETA1>(my_prf + (K + a) * PS, e);
-        wave_ntt(e, L.xch, tw);
-        int t[4];
-#pragma unroll
-        for (int m = 0; m < 4; m++) t[m] = canon16(fqmul(mont_reduce(acc[m]), MONT2) + barrett16(e[m]));
-        emit_encode12(L.cbuf, t, my_ek + 384 * a, my_dk + 384 * K + 384 * a);
-    }
-    if (l < 8) {
-        const uint32_t r = reinterpret_cast<const uint32_t*>(rho + item * 32)[l];
-        reinterpret_cast<uint32_t*>(my_ek + 384 * K)[l] = r;
-        reinterpret_cast<uint32_t*>(my_dk + 768 * K)[l] = r;
-    }
-}
-
-// ================================================================================================
-// stand-alone primitives (C-ABI: mlkem_ntt / mlkem_intt / mlkem_multiply_ntts / mlkem_sample_cbd)
-// ================================================================================================
-// One polynomial per wave, grid-stride.  In/out uint16, canonical output (ml_kem.c:287 / :336).
-template <bool INVERSE>
-__global__ void __launch_bounds__(WAVE * ARITH_WAVES) k_ntt_batch(size_t n, const uint16_t* __restrict__ in, uint16_t* __restrict__ out) {
-    __shared__ __attribute__((aligned(16))) int16_t xch_all[ARITH_WAVES][256];
-    const int wv = (int)(threadIdx.x >> 6);
-    NttTwiddles tw;
-    load_twiddles(tw);
-    const size_t stride = (size_t)gridDim.x * ARITH_WAVES;
-    for (size_t p = (size_t)blockIdx.x * ARITH_WAVES + wv; p < n; p += stride) {
-        int x[4];
-        load_poly_nat(in + p * 256, x);
-#pragma unroll
-        for (int m = 0; m < 4; m++) x[m] &= 0xFFF;   // 12-bit fields of the reference's union integer
-        if constexpr (INVERSE) wave_intt(x, xch_all[wv], tw, INTT_FINAL_PLAIN);
-        else wave_ntt(x, xch_all[wv], tw);
-#pragma unroll
-        for (int m = 0; m < 4; m++) x[m] = canon16(x[m]);
-        store_poly_nat(out + p * 256, x);
-    }
-}
-
-// MultiplyNTTs (ml_kem.c:415-442): h = a o b, one polynomial pair per wave
-__global__ void __launch_bounds__(WAVE * ARITH_WAVES) k_basemul_batch(size_t n, const uint16_t* __restrict__ a, const uint16_t* __restrict__ b,
-                                                                      uint16_t* __restrict__ h) {
-    __shared__ __attribute__((aligned(16))) int16_t vh_all[ARITH_WAVES][256];
-    __shared__ __attribute__((aligned(16))) int16_t vg_all[ARITH_WAVES][128];
-    const int wv = (int)(threadIdx.x >> 6);
-    NttTwiddles tw;
-    load_twiddles(tw);
-    const size_t stride = (size_t)gridDim.x * ARITH_WAVES;
-    for (size_t p = (size_t)blockIdx.x * ARITH_WAVES + wv; p < n; p += stride) {
-        int av[4], bv[4], acc[4] = {0, 0, 0, 0};
-        load_poly_nat(a + p * 256, av);
-        load_poly_nat(b + p * 256, bv);
-#pragma unroll
-        for (int m = 0; m < 4; m++) { av[m] &= 0xFFF; bv[m] = barrett16(bv[m] & 0xFFF); }
-        stash_vhat(vh_all[wv], vg_all[wv], bv, tw);
-        wave_lds_fence();
-        basemul_acc(acc, av, vh_all[wv], vg_all[wv]);
-        wave_lds_fence();
-#pragma unroll
-        for (int m = 0; m < 4; m++) av[m] = canon16(fqmul(mont_reduce(acc[m]), MONT2));
-        store_poly_nat(h + p * 256, av);
-    }
-}
-
-// SamplePolyCBD (ml_kem.c:253-275): bytes [n][64*eta] -> canonical uint16 polynomials
-template <int ETA>
-__global__ void __launch_bounds__(WAVE * ARITH_WAVES) k_cbd_batch(size_t n, const uint8_t* __restrict__ bytes, uint16_t* __restrict__ out) {
-    const int wv = (int)(threadIdx.x >> 6);
-    const size_t stride = (size_t)gridDim.x * ARITH_WAVES;
-    for (size_t p = (size_t)blockIdx.x * ARITH_WAVES + wv; p < n; p += stride) {
-        int x[4];
-        cbd_nat<ETA>(bytes + p * 64 * ETA, x);
-#pragma unroll
-        for (int m = 0; m < 4; m++) x[m] += (x[m] >> 31) & KQ;
-        store_poly_nat(out + p * 256, x);
     }
 }
 

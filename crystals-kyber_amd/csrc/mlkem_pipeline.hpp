@@ -13,6 +13,7 @@
 #pragma once
 #include "mlkem_kernels.hpp"
 #include "mlkem_sampler.hpp"
+#include "mlkem_arith.hpp"
 #ifndef MLKEM_EMU
 #include <vector>
 #endif

@@ -28,6 +28,8 @@ static thread_local emu_dim3 threadIdx, blockIdx, gridDim, blockDim;
 
 struct uint2 { uint32_t x, y; };
 struct alignas(16) uint4 { uint32_t x, y, z, w; };
+struct alignas(8) float2 { float x, y; };
+struct alignas(16) float4 { float x, y, z, w; };
 
 namespace emu {
 struct WaveCtx {

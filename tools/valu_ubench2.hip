@@ -71,6 +71,30 @@ KERNEL(k_mov, "v_mov_b32 %0, %1")
 KERNEL(k_sad, "v_sad_u32 %0, %0, %1, %2")
 KERNEL(k_xad, "v_xad_u32 %0, %0, %1, %2")
 KERNEL(k_mul_hi_i32, "v_mul_hi_i32 %0, %0, %1")
+KERNEL(k_fmamk, "v_fmamk_f32 %0, %0, 0x39a02c79, %1")
+KERNEL(k_fmaak, "v_fmaak_f32 %0, %0, %1, 0x4b400000")
+KERNEL(k_fmac, "v_fmac_f32 %0, %1, %2")
+#define KERNEL64(NAME, ASM)                                                                                 \
+    __global__ void __launch_bounds__(256) NAME(uint32_t* out, int iters) {                                 \
+        unsigned long long r[16];                                                                           \
+        _Pragma("unroll") for (int i = 0; i < 16; i++) r[i] = (threadIdx.x * 2654435761ull + i * 40503u + blockIdx.x) * 0x100000001ull; \
+        BODY(ASM)                                                                                           \
+        unsigned long long acc = 0;                                                                         \
+        _Pragma("unroll") for (int i = 0; i < 16; i++) acc ^= r[i];                                         \
+        out[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)(acc ^ (acc >> 32));                         \
+    }
+KERNEL64(k_pk_fma_f32, "v_pk_fma_f32 %0, %0, %1, %2")
+KERNEL64(k_pk_add_f32, "v_pk_add_f32 %0, %0, %1")
+KERNEL64(k_pk_mul_f32, "v_pk_mul_f32 %0, %0, %1")
+KERNEL(k_fma_sgpr, "v_fma_f32 %0, %0, s4, %1")
+KERNEL(k_add_lit, "v_add_f32 %0, 0x4b400000, %0")
+KERNEL(k_cvt_sdwa, "v_cvt_f32_u32_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1")
+KERNEL(k_cmp_cnd, "v_cmp_gt_f32 vcc, 0, %1\n\tv_cndmask_b32 %0, %0, %2, vcc")
+KERNEL(k_max_f32, "v_max_f32 %0, %0, %1")
+KERNEL(k_min_f32, "v_min_f32 %0, %0, %1")
+KERNEL(k_floor_f32, "v_floor_f32 %0, %0")
+KERNEL(k_xor_lit, "v_xor_b32 %0, 0x12345678, %0")
+KERNEL(k_and_or2, "v_and_b32 %0, %0, %1\n\tv_or_b32 %0, %0, %2")
 
 typedef void (*kfn_t)(uint32_t*, int);
 double run(const char* name, kfn_t k, double ref_ns) {
@@ -102,6 +126,9 @@ int main() {
     RUN(k_mul_u24); RUN(k_mul_i24); RUN(k_mul_hi_u24); RUN(k_mad_u24); RUN(k_mad_i24); RUN(k_mul_lo); RUN(k_mul_hi); RUN(k_mul_hi_i32);
     RUN(k_mul_lo_u16); RUN(k_mad_u16); RUN(k_pk_add_u16); RUN(k_pk_mul_lo_u16); RUN(k_pk_mad_u16); RUN(k_pk_sub_i16); RUN(k_pk_min_i16);
     RUN(k_pk_ashr_i16); RUN(k_fma_f32); RUN(k_mul_f32); RUN(k_add_f32); RUN(k_rndne_f32); RUN(k_cvt_f32_i32); RUN(k_cvt_i32_f32);
-    RUN(k_mad_i32_i16); RUN(k_dot2_i32_i16); RUN(k_cndmask); RUN(k_mov); RUN(k_sad); RUN(k_xad);
+    RUN(k_mad_i32_i16); RUN(k_dot2_i32_i16); RUN(k_mov); RUN(k_sad); RUN(k_xad);
+    RUN(k_fmamk); RUN(k_fmaak); RUN(k_fmac); RUN(k_pk_fma_f32); RUN(k_pk_add_f32); RUN(k_pk_mul_f32); RUN(k_fma_sgpr); RUN(k_add_lit);
+    RUN(k_cvt_sdwa); RUN(k_cmp_cnd); RUN(k_max_f32); RUN(k_min_f32); RUN(k_floor_f32); RUN(k_xor_lit); RUN(k_and_or2);
+    ref = run("k_xor(again)", k_xor, 0); RUN(k_add); RUN(k_fma_f32); RUN(k_bitop3); RUN(k_alignbit_c);
     return 0;
 }
