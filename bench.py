@@ -182,7 +182,7 @@ def run_kem(args, pset, rank, world, device):
             torch.cuda.synchronize(device)
         rows = {k: {"ms_total": v[0], "launches": v[1], "ms_avg": v[0] / max(v[1], 1)} for k, v in kt.rows.items()}
         extra["kernels"] = rows
-        extra["chunk_items"] = args.chunk or int(os.environ.get("MLKEM_CHUNK_ITEMS", 1 << 17))
+        extra["chunk_items"] = args.chunk or int(os.environ.get("MLKEM_CHUNK_ITEMS", 1 << 18))
         if world == 1 and not args.no_cpu:
             extra["cpu_baseline"] = cpu_baseline(pset, ek, dk, m, c, K)
     eng.close()

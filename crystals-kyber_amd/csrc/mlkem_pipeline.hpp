@@ -93,13 +93,65 @@ inline bool param_set(int set, ParamSet& p) {
 //   prf      (2k+1)*PS raw PRF output rows (PS = 192 for eta1 = 3, else 128)
 //   leftover 4*(k*k)   sponge indices needing a 4th squeeze block (+1 counter word)
 // Per h-chunk item: r, rho, m, Kp, Kbar : 32 bytes each.
+#ifdef MLKEM_EMU
+using event_t = void*;
+inline void ev_record(event_t, stream_t) {}
+inline void stream_wait(stream_t, event_t) {}
+#else
+using event_t = hipEvent_t;
+inline void ev_record(event_t e, stream_t s) { (void)hipEventRecord(e, s); }
+inline void stream_wait(stream_t s, event_t e) { (void)hipStreamWaitEvent(s, e, 0); }
+#endif
+
 struct Workspace {
-    uint16_t* A = nullptr;
+    uint16_t* A = nullptr;      // current chunk buffer (set by view())
     uint8_t *prf = nullptr, *r = nullptr, *rho = nullptr, *m = nullptr, *Kp = nullptr, *Kbar = nullptr;
     uint32_t* leftover = nullptr;
+    // the chunk scratch exists twice so that the sampler of chunk i+1 (caller's stream) can run while the
+    // arithmetic kernel of chunk i (helper stream) still reads chunk i's matrix: ChunkPipe below
+    uint16_t* A2[2] = {nullptr, nullptr};
+    uint8_t* prf2[2] = {nullptr, nullptr};
+    uint32_t* leftover2[2] = {nullptr, nullptr};
+    stream_t helper = nullptr;                        // nullptr: no overlap, everything on the caller's stream
+    event_t ev_sample[2] = {nullptr, nullptr}, ev_free[2] = {nullptr, nullptr};
     size_t cap = 0;    // chunk capacity (items) of A / prf / leftover
     size_t hcap = 0;   // h-chunk capacity (items) of the 32-byte arrays
     int ring = 64;     // sampler LDS ring size (64 or 128 coefficients per lane)
+    Workspace view(int b) const {
+        Workspace w = *this;
+        w.A = A2[b]; w.prf = prf2[b]; w.leftover = leftover2[b];
+        return w;
+    }
+};
+
+// Two-stream software pipeline over the chunks of one h-chunk: sampler on `main`, polynomial arithmetic on the helper
+// stream, two scratch buffers, fork/join by events (capturable in a hipGraph; no host synchronisation).
+struct ChunkPipe {
+    const Workspace& ws;
+    stream_t main;
+    bool overlap;
+    int i = 0;
+    ChunkPipe(const Workspace& w, stream_t st, size_t nchunks) : ws(w), main(st), overlap(w.helper != nullptr && nchunks > 1) {}
+    int begin_chunk() {                       // buffer for the next chunk; `main` waits until its previous user is done
+        const int b = overlap ? (i & 1) : 0;
+        if (overlap && i >= 2) stream_wait(main, ws.ev_free[b]);
+        return b;
+    }
+    stream_t arith_stream(int b) {            // stream for the arithmetic kernel, ordered behind the sampler
+        if (!overlap) return main;
+        ev_record(ws.ev_sample[b], main);
+        stream_wait(ws.helper, ws.ev_sample[b]);
+        return ws.helper;
+    }
+    void end_chunk(int b) {
+        if (overlap) ev_record(ws.ev_free[b], ws.helper);
+        i++;
+    }
+    void join() {                             // `main` continues only after every arithmetic kernel has finished
+        if (!overlap) return;
+        stream_wait(main, ws.ev_free[0]);
+        if (i >= 2) stream_wait(main, ws.ev_free[1]);
+    }
 };
 
 inline size_t ceil_div(size_t a, size_t b) { return (a + b - 1) / b; }
@@ -137,12 +189,18 @@ inline void keygen_run(stream_t st, const ParamSet& p, size_t n, const uint8_t* 
     for (size_t h0 = 0; h0 < n; h0 += ws.hcap) {
         const size_t hn = min_sz(ws.hcap, n - h0);
         launch("k_hash_keygen_seed", k_hash_keygen_seed<K>, ceil_div(hn, WAVE), WAVE, st, hn, d + h0 * 32, ws.rho, ws.r);
+        ChunkPipe pipe(ws, st, ceil_div(hn, ws.cap));
         for (size_t c0 = 0; c0 < hn; c0 += ws.cap) {
             const size_t cn = min_sz(ws.cap, hn - c0), i0 = h0 + c0;
-            launch_sample(st, p, cn, ws.rho + c0 * 32, 32, /*transpose=*/0, ws.r + c0 * 32, 2 * K, 2 * K, ws);
-            launch("k_keygen", k_keygen<K, ETA1>, ceil_div(cn, ARITH_WAVES), WAVE * ARITH_WAVES, st, cn, (const uint16_t*)ws.A,
-                   (const uint8_t*)ws.prf, (const uint8_t*)(ws.rho + c0 * 32), ek + i0 * p.ek_len, dk + i0 * p.dk_len);
+            const int buf = pipe.begin_chunk();
+            const Workspace w = ws.view(buf);
+            launch_sample(st, p, cn, ws.rho + c0 * 32, 32, /*transpose=*/0, ws.r + c0 * 32, 2 * K, 2 * K, w);
+            launch("k_keygen", k_keygen<K, ETA1>, ceil_div(cn, ARITH_WAVES), WAVE * ARITH_WAVES, pipe.arith_stream(buf), cn,
+                   (const uint16_t*)w.A, (const uint8_t*)w.prf, (const uint8_t*)(ws.rho + c0 * 32), ek + i0 * p.ek_len,
+                   dk + i0 * p.dk_len);
+            pipe.end_chunk(buf);
         }
+        pipe.join();
         launch("k_hash_keygen_fin", k_hash_keygen_fin<K>, ceil_div(hn, WAVE), WAVE, st, hn, (const uint8_t*)(ek + h0 * p.ek_len),
                z + h0 * 32, dk + h0 * p.dk_len);
     }
@@ -155,14 +213,19 @@ inline void encaps_run(stream_t st, const ParamSet& p, size_t n, const uint8_t* 
     for (size_t h0 = 0; h0 < n; h0 += ws.hcap) {
         const size_t hn = min_sz(ws.hcap, n - h0);
         launch("k_hash_encaps", k_hash_encaps<K>, ceil_div(hn, WAVE), WAVE, st, hn, ek + h0 * p.ek_len, m + h0 * 32, Kout + h0 * 32, ws.r);
+        ChunkPipe pipe(ws, st, ceil_div(hn, ws.cap));
         for (size_t c0 = 0; c0 < hn; c0 += ws.cap) {
             const size_t cn = min_sz(ws.cap, hn - c0), i0 = h0 + c0;
             const uint8_t* eki = ek + i0 * p.ek_len;
-            launch_sample(st, p, cn, eki + 384 * K, p.ek_len, /*transpose=*/1, ws.r + c0 * 32, 2 * K + 1, K, ws);
-            launch("k_encrypt", k_encrypt<K, ETA1, DU, DV, false>, ceil_div(cn, ARITH_WAVES), WAVE * ARITH_WAVES, st, cn, eki,
-                   (size_t)p.ek_len, m + i0 * 32, (const uint16_t*)ws.A, (const uint8_t*)ws.prf, c + i0 * p.c_len,
-                   (const uint8_t*)nullptr, (const uint8_t*)nullptr, (const uint8_t*)nullptr, (uint8_t*)nullptr);
+            const int buf = pipe.begin_chunk();
+            const Workspace w = ws.view(buf);
+            launch_sample(st, p, cn, eki + 384 * K, p.ek_len, /*transpose=*/1, ws.r + c0 * 32, 2 * K + 1, K, w);
+            launch("k_encrypt", k_encrypt<K, ETA1, DU, DV, false>, ceil_div(cn, ARITH_WAVES), WAVE * ARITH_WAVES,
+                   pipe.arith_stream(buf), cn, eki, (size_t)p.ek_len, m + i0 * 32, (const uint16_t*)w.A, (const uint8_t*)w.prf,
+                   c + i0 * p.c_len, (const uint8_t*)nullptr, (const uint8_t*)nullptr, (const uint8_t*)nullptr, (uint8_t*)nullptr);
+            pipe.end_chunk(buf);
         }
+        pipe.join();
     }
 }
 
@@ -184,15 +247,20 @@ inline void decaps_run(stream_t st, const ParamSet& p, size_t n, const uint8_t* 
         else
             launch("k_hash_decaps", k_hash_decaps<K, CLEN, false>, ceil_div(hn, WAVE), WAVE, st, hn, dkh, ch, (const uint8_t*)ws.m, ws.Kp,
                    ws.r, ws.Kbar, (int32_t*)nullptr);
+        ChunkPipe pipe(ws, st, ceil_div(hn, ws.cap));
         for (size_t c0 = 0; c0 < hn; c0 += ws.cap) {
             const size_t cn = min_sz(ws.cap, hn - c0), i0 = h0 + c0;
             const uint8_t* dki = dk + i0 * p.dk_len;
-            launch_sample(st, p, cn, dki + 768 * K, p.dk_len, /*transpose=*/1, ws.r + c0 * 32, 2 * K + 1, K, ws);
-            launch("k_encrypt_cmp", k_encrypt<K, ETA1, DU, DV, true>, ceil_div(cn, ARITH_WAVES), WAVE * ARITH_WAVES, st, cn,
-                   dki + 384 * K, (size_t)p.dk_len, (const uint8_t*)(ws.m + c0 * 32), (const uint16_t*)ws.A, (const uint8_t*)ws.prf,
-                   (uint8_t*)nullptr, c + i0 * p.c_len, (const uint8_t*)(ws.Kp + c0 * 32), (const uint8_t*)(ws.Kbar + c0 * 32),
-                   Kout + i0 * 32);
+            const int buf = pipe.begin_chunk();
+            const Workspace w = ws.view(buf);
+            launch_sample(st, p, cn, dki + 768 * K, p.dk_len, /*transpose=*/1, ws.r + c0 * 32, 2 * K + 1, K, w);
+            launch("k_encrypt_cmp", k_encrypt<K, ETA1, DU, DV, true>, ceil_div(cn, ARITH_WAVES), WAVE * ARITH_WAVES,
+                   pipe.arith_stream(buf), cn, dki + 384 * K, (size_t)p.dk_len, (const uint8_t*)(ws.m + c0 * 32), (const uint16_t*)w.A,
+                   (const uint8_t*)w.prf, (uint8_t*)nullptr, c + i0 * p.c_len, (const uint8_t*)(ws.Kp + c0 * 32),
+                   (const uint8_t*)(ws.Kbar + c0 * 32), Kout + i0 * 32);
+            pipe.end_chunk(buf);
         }
+        pipe.join();
     }
 }
 

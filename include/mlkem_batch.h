@@ -55,7 +55,7 @@ const char* mlkem_last_hip_error(void);
 
 /* ---- engine context: owns the scratch HBM of one device --------------------------------------------- */
 typedef struct mlkem_ctx mlkem_ctx;
-/* `chunk_items` = items processed per kernel sequence (0 = default 2^20); scratch is
+/* `chunk_items` = items per sampler/arithmetic chunk (0 = default 2^18, env MLKEM_CHUNK_ITEMS); scratch is
  * ~10 KiB x chunk_items, allocated once here so that no *_dev call allocates. */
 int mlkem_ctx_create(mlkem_ctx** out, int device, size_t chunk_items);
 void mlkem_ctx_destroy(mlkem_ctx* ctx);

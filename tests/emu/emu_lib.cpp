@@ -20,9 +20,12 @@ static Workspace make_ws(size_t n) {
     ws.hcap = g_hcap ? g_hcap : (n ? n : 1);
     if (ws.hcap < ws.cap) ws.hcap = ws.cap;
     ws.ring = g_ring;
-    ws.A = (uint16_t*)xalloc(ws.cap * 16 * 512);
-    ws.prf = (uint8_t*)xalloc(ws.cap * 9 * 192);
-    ws.leftover = (uint32_t*)xalloc((ws.cap * 16 + 1) * 4);
+    for (int b = 0; b < 2; b++) {
+        ws.A2[b] = (uint16_t*)xalloc(ws.cap * 16 * 512);
+        ws.prf2[b] = (uint8_t*)xalloc(ws.cap * 9 * 192);
+        ws.leftover2[b] = (uint32_t*)xalloc((ws.cap * 16 + 1) * 4);
+    }
+    ws.A = ws.A2[0]; ws.prf = ws.prf2[0]; ws.leftover = ws.leftover2[0];
     ws.r = (uint8_t*)xalloc(ws.hcap * 32);
     ws.rho = (uint8_t*)xalloc(ws.hcap * 32);
     ws.m = (uint8_t*)xalloc(ws.hcap * 32);
@@ -31,7 +34,8 @@ static Workspace make_ws(size_t n) {
     return ws;
 }
 static void free_ws(Workspace& ws) {
-    free(ws.A); free(ws.prf); free(ws.leftover); free(ws.r); free(ws.rho); free(ws.m); free(ws.Kp); free(ws.Kbar);
+    for (int b = 0; b < 2; b++) { free(ws.A2[b]); free(ws.prf2[b]); free(ws.leftover2[b]); }
+    free(ws.r); free(ws.rho); free(ws.m); free(ws.Kp); free(ws.Kbar);
 }
 
 extern "C" {
@@ -70,7 +74,7 @@ int emu_sample_matrix(int k, size_t n, const uint8_t* rho, int transpose, uint16
     param_set(k == 2 ? 512 : k == 3 ? 768 : 1024, p);
     uint8_t* r = (uint8_t*)xalloc(n * 32);
     for (size_t i = 0; i < n * 32; i++) r[i] = (uint8_t)i;
-    launch_sample(nullptr, p, n, rho, 32, transpose, r, 2 * k + 1, k, ws);
+    launch_sample(nullptr, p, n, rho, 32, transpose, r, 2 * k + 1, k, ws.view(0));
     memcpy(A_out, ws.A, n * (size_t)(k * k) * 512);
     int left = (int)ws.leftover[0];
     free(r);
