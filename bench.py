@@ -257,7 +257,7 @@ def main():
         elapsed, ok, extra = run_ntt(args, rank, world, device)
         metric, unit = "batched forward+inverse NTT polynomials/sec at batch 2^20", "polys/s"
         wl = "configs[1]: batched forward+inverse NTT only, %d polynomials per GPU" % args.batch
-        dtype = "int16/int32"
+        dtype = "f32 (exact integer arithmetic < 2^24), u16 I/O"
     else:
         pset = 768 if args.workload == "kem768" else 1024
         elapsed, ok, extra = run_kem(args, pset, rank, world, device)
@@ -267,7 +267,7 @@ def main():
         else:
             metric, unit = "ML-KEM-1024 keygen+encaps+decaps/sec at batch 2^20", "triples/s"
             wl = "configs[3]: ML-KEM-1024 KeyGen+Encaps+Decaps, batch %d per GPU" % args.batch
-        dtype = "u32/int32 (64-bit Keccak lanes as 2 x u32, mod-3329 arithmetic in int32, u8/u16 I/O)"
+        dtype = "u32+f32 (64-bit Keccak lanes as 2 x u32; mod-3329 arithmetic exact on integers < 2^24 in the fp32 pipe; u8/u16 I/O)"
 
     if rank != 0:
         return
@@ -278,14 +278,32 @@ def main():
     achieved = value / world * algo / 1e9          # per-GPU algorithmic GB/s
     kernels = extra.get("kernels", {})
     dom = max(kernels.items(), key=lambda kv: kv[1]["ms_total"])[0] if kernels else None
+    if args.workload == "ntt" and dom:
+        # NTT-only: each of the two kernels (forward, inverse) handles a whole unit half: 1024 algorithmic bytes per
+        # polynomial and launch; the roofline entry is the dominant kernel's, from its own HIP-event duration.
+        per_launch = 1024.0 * args.batch
+        achieved = per_launch / (kernels[dom]["ms_avg"] * 1e-3) / 1e9
+        scope = "dominant kernel %s: 1024 B/polynomial x %d polynomials per launch / its average HIP-event duration; " \
+                "whole step (fwd+inv, 2048 B/poly) = %.1f GB/s" % (dom, args.batch, value / world * algo / 1e9)
+    else:
+        scope = "whole pass (all kernels of one step, no single kernel covers a unit); algorithmic bytes = %d B/unit x %d units " \
+                "per step / step time" % (algo, args.batch)
     roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
-                "scope": "whole pass (all kernels of one step); algorithmic bytes = %d B/unit x %d units per step" % (algo, args.batch),
+                "traffic": None, "scope": scope,
                 "dominant_kernel": dom,
                 "dominant_kernel_ms_avg": kernels[dom]["ms_avg"] if dom else None,
                 "dominant_kernel_share": kernels[dom]["ms_total"] / sum(k["ms_total"] for k in kernels.values()) if dom else None}
+    # HBM traffic from the PMC counters is collected off-line (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE cannot run inside
+    # this process); the committed summary of the same command is attached when it matches the workload and batch
+    tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic_%s.json" % args.workload)
+    if os.path.exists(tpath) and args.batch == 1 << 20:
+        t = json.load(open(tpath))
+        roofline["traffic"] = t["hbm_bytes_per_step_corrected"]
+        roofline["traffic_note"] = "bytes per step from %s: (2*FETCH_SIZE + WRITE_SIZE)*1024; raw = %.3g" % (
+            os.path.relpath(tpath, ROOT), t["hbm_bytes_per_step_raw"])
     if args.workload == "kem768":
-        # the bound that actually binds: 95 Keccak-f per pair x 4320 32-bit VALU lane-ops, + ~0.3 M for NTT/codec
+        # the bound that actually binds: 95 Keccak-f per pair x 24 rounds x 180 VALU (122 full-rate + 58
+        # v_alignbit_b32 at ~0.58x rate, profiles/r01_valu_ubench.txt), + NTT / codec / sampling work
         keccak_ops = 95 * KECCAK_PERM_LANE_OPS
         roofline["binding"] = {"bound": "valu-int32", "keccak_lane_ops_per_pair": keccak_ops,
                                "keccak_lane_ops_per_s": value / world * keccak_ops,
