@@ -2,7 +2,7 @@
 """bench.py — BASELINE.json's headline metric on MI355X:
 ML-KEM-768 encaps+decaps pairs per second at batch 2^20 (BASELINE configs[2]), inputs resident in HBM.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload kem768|ntt|kem1024]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload kem768|kem1024|kem512|ntt]
 
 One "step" = one pass of the hot path over one batch: Encaps_internal over 2^20 (ek, m) followed by KEM_Decaps
 (hash check included, as the reference's public API does) over the 2^20 (dk, c) it produced.  Keys come from the
@@ -35,7 +35,7 @@ import __graft_entry__ as ge  # noqa: E402
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 VALU_PEAK_LANE_OPS = 256 * 4 * 32 * 2.4e9   # 256 CU x 4 SIMD-32 x 2.4 GHz (one 32-bit integer op per lane-clock)
 BENCH_SEED = 0xC0FFEE
-ALGO_BYTES = {"kem768": 5856, "kem1024": 12768, "ntt": 2048}   # SURVEY 8d / BASELINE.md section 4
+ALGO_BYTES = {"kem768": 5856, "kem1024": 12768, "kem512": 6560, "ntt": 2048}   # SURVEY 8d / BASELINE.md section 4
 # 32-bit VALU lane-operations per unit, from the ISA of this build
 KECCAK_PERM_LANE_OPS = 24 * 180
 
@@ -146,7 +146,7 @@ def run_kem(args, pset, rank, world, device):
     K = torch.empty((n, 32), dtype=torch.uint8, device=device)
     K2 = torch.empty((n, 32), dtype=torch.uint8, device=device)
     st = torch.empty(n, dtype=torch.int32, device=device)
-    timed_keygen = args.workload == "kem1024"
+    timed_keygen = args.workload in ("kem1024", "kem512")
 
     def step():
         if timed_keygen:
@@ -241,7 +241,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="kem768", choices=("kem768", "kem1024", "ntt"))
+    ap.add_argument("--workload", default="kem768", choices=("kem768", "kem1024", "kem512", "ntt"))
     ap.add_argument("--batch", type=int, default=1 << 20, help="items per GPU per step (BASELINE: 2^20)")
     ap.add_argument("--chunk", type=int, default=0, help="engine chunk size in items (0 = library default)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
@@ -259,14 +259,14 @@ def main():
         wl = "configs[1]: batched forward+inverse NTT only, %d polynomials per GPU" % args.batch
         dtype = "f32 (exact integer arithmetic < 2^24), u16 I/O"
     else:
-        pset = 768 if args.workload == "kem768" else 1024
+        pset = {"kem768": 768, "kem1024": 1024, "kem512": 512}[args.workload]
         elapsed, ok, extra = run_kem(args, pset, rank, world, device)
         if args.workload == "kem768":
             metric, unit = "ML-KEM-768 encaps+decaps/sec at batch 2^20; achieved HBM GB/s vs peak", "pairs/s"
             wl = "configs[2]: ML-KEM-768 full Encaps+Decaps (KEM_Decaps incl. dk hash check), batch %d per GPU, keys from batch KeyGen (untimed)" % args.batch
         else:
-            metric, unit = "ML-KEM-1024 keygen+encaps+decaps/sec at batch 2^20", "triples/s"
-            wl = "configs[3]: ML-KEM-1024 KeyGen+Encaps+Decaps, batch %d per GPU" % args.batch
+            metric, unit = "ML-KEM-%d keygen+encaps+decaps/sec at batch 2^20" % pset, "triples/s"
+            wl = "%sML-KEM-%d KeyGen+Encaps+Decaps, batch %d per GPU" % ("configs[3]: " if pset == 1024 else "", pset, args.batch)
         dtype = "u32+f32 (64-bit Keccak lanes as 2 x u32; mod-3329 arithmetic exact on integers < 2^24 in the fp32 pipe; u8/u16 I/O)"
 
     if rank != 0:
