@@ -44,19 +44,30 @@ __device__ __forceinline__ uint2 load_qword_tail(const uint8_t* p, unsigned avai
     return v;
 }
 
+// The stage holds STAGE_ROWS rows at a time (a rate block of the wave is staged in 64 / STAGE_ROWS parts): 32 rows keep
+// the LDS footprint at 5.3 KB per wave so that occupancy is set by registers, not by LDS.
+#ifndef MLKEM_STAGE_ROWS
+#define MLKEM_STAGE_ROWS 32
+#endif
+constexpr int STAGE_ROWS = MLKEM_STAGE_ROWS;
+constexpr int STAGE_PARTS = WAVE / STAGE_ROWS;
+
 template <int RATE>
-__device__ __forceinline__ void wave_stage_block(uint2* stage, const MsgView& mv, size_t item0, size_t n_items, unsigned voff) {
-    constexpr int NQ = RATE / 8;
+__device__ __forceinline__ void wave_stage_block(uint2* stage, const MsgView& mv, size_t item0, size_t n_items, unsigned voff,
+                                                 int part) {
+    constexpr int NQ = RATE / 8, TOT = STAGE_ROWS * NQ, ITERS = (TOT + WAVE - 1) / WAVE;
     const unsigned l = (unsigned)lane_id(), total = mv.len0 + mv.len1;
     // loads are issued in groups of 7 (7 x 8 B per lane in flight): enough memory-level parallelism without
     // pushing the kernel past 128 VGPRs next to the 50-register Keccak state
 #pragma unroll 1
-    for (int it0 = 0; it0 < NQ; it0 += 7)
+    for (int it0 = 0; it0 < ITERS; it0 += 7)
 #pragma unroll
     for (int it = it0; it < it0 + 7; it++) {
-        if (it >= NQ) break;
-        const unsigned f = (unsigned)it * WAVE + l, row = f / NQ, col = f - row * NQ;
-        size_t item = item0 + row;
+        if (it >= ITERS) break;
+        const unsigned f = (unsigned)it * WAVE + l;
+        if (TOT % WAVE != 0 && f >= (unsigned)TOT) break;
+        const unsigned row = f / NQ, col = f - row * NQ;
+        size_t item = item0 + (size_t)(part * STAGE_ROWS) + row;
         if (item >= n_items) item = n_items - 1;   // rows beyond the batch are computed but never stored
         const unsigned pos = voff + 8u * col;
         uint2 v;
@@ -69,16 +80,31 @@ __device__ __forceinline__ void wave_stage_block(uint2* stage, const MsgView& mv
     }
 }
 
-// XOR this lane's staged row (RATE bytes) into its state
+// XOR the staged row (RATE bytes) of every lane that belongs to part `part` into its state
 template <int RATE>
-__device__ __forceinline__ void lane_xor_row(KeccakState& s, const uint2* stage) {
+__device__ __forceinline__ void lane_xor_row(KeccakState& s, const uint2* stage, int part) {
     constexpr int NQ = RATE / 8;
-    const uint2* row = stage + lane_id() * NQ;
+    const int l = lane_id();
+    if (l / STAGE_ROWS == part) {
+        const uint2* row = stage + (l % STAGE_ROWS) * NQ;
 #pragma unroll
-    for (int w = 0; w < NQ; w++) {
-        const uint2 v = row[w];
-        s.lo[w] ^= v.x;
-        s.hi[w] ^= v.y;
+        for (int w = 0; w < NQ; w++) {
+            const uint2 v = row[w];
+            s.lo[w] ^= v.x;
+            s.hi[w] ^= v.y;
+        }
+    }
+}
+// stage + XOR one rate block (or the final partial block) for all 64 lanes
+template <int RATE>
+__device__ __forceinline__ void wave_absorb_block(KeccakState& s, uint2* stage, const MsgView& mv, size_t item0, size_t n_items,
+                                                  unsigned voff) {
+#pragma unroll 1
+    for (int part = 0; part < STAGE_PARTS; part++) {
+        wave_stage_block<RATE>(stage, mv, item0, n_items, voff, part);
+        wave_lds_fence();
+        lane_xor_row<RATE>(s, stage, part);
+        wave_lds_fence();
     }
 }
 
@@ -106,26 +132,18 @@ __device__ __forceinline__ void wave_sponge_absorb(KeccakState& s, uint2* stage,
     keccak_zero(s);
     unsigned voff = 0;
     while (total - voff >= (unsigned)RATE) {
-        wave_stage_block<RATE>(stage, mv, item0, n_items, voff);
-        wave_lds_fence();
-        lane_xor_row<RATE>(s, stage);
-        wave_lds_fence();
+        wave_absorb_block<RATE>(s, stage, mv, item0, n_items, voff);
         keccak_f1600(s);
         voff += RATE;
     }
     const unsigned rem = total - voff;
-    if (rem) {
-        wave_stage_block<RATE>(stage, mv, item0, n_items, voff);
-        wave_lds_fence();
-        lane_xor_row<RATE>(s, stage);
-        wave_lds_fence();
-    }
+    if (rem) wave_absorb_block<RATE>(s, stage, mv, item0, n_items, voff);
     keccak_xor_byte_rt(s, rem, SUFFIX);
     keccak_xor_byte<RATE - 1>(s, 0x80);
     keccak_f1600(s);
 }
 
-constexpr int STAGE_QWORDS = WAVE * (168 / 8);   // largest rate (SHAKE128): 10752 bytes per wave
+constexpr int STAGE_QWORDS = STAGE_ROWS * (168 / 8);   // largest rate (SHAKE128): 5376 bytes per wave at 32 rows
 
 // store / load 8 dwords (32 bytes) of per-item data: row `item` of a [n][32]-byte array
 __device__ __forceinline__ void store32(uint8_t* base, size_t stride, size_t item, const uint32_t (&w)[8]) {

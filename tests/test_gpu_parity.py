@@ -345,3 +345,25 @@ def test_ml_kem_h_dropin_shim(pkg, tmp_path):
     assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
     assert "Test successful" in r.stdout and r.stdout.count("ML-KEM-") == 3
     assert "Type check failed" in r.stderr and "Hash check failed" in r.stderr
+
+
+@pytest.mark.parametrize("env", ({"MLKEM_OVERLAP": "1"}, {"MLKEM_RING": "128"}, {"MLKEM_HCHUNK_ITEMS": "300"}))
+def test_engine_options_do_not_change_results(pkg, torch, oracle, env, monkeypatch):
+    """Opt-in execution modes read at context creation: two-stream sampler/arithmetic overlap, the 128-coefficient
+    sampler ring, small h-chunks.  Same bytes out."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    e = pkg.MLKEM(768, device=0, chunk_items=128)     # several chunks (and h-chunks) per call
+    n = 700
+    d, z, m = seeds("opt-d", n, 3), seeds("opt-z", n, 3), seeds("opt-m", n, 3)
+    ek, dk = e.keygen(dev(torch, d), dev(torch, z))
+    c, K = e.encaps(ek, dev(torch, m))
+    cb = host(c).copy()
+    cb[::50, 9] ^= 0x10
+    Kd, st = e.decaps(dk, dev(torch, cb))
+    ek_o, dk_o = oracle.keygen(768, d, z)
+    c_o, K_o = oracle.encaps(768, ek_o, m)
+    Kd_o, st_o = oracle.decaps(768, dk_o, cb)
+    assert (host(ek) == ek_o).all() and (host(dk) == dk_o).all() and (host(c) == c_o).all() and (host(K) == K_o).all()
+    assert (host(Kd) == Kd_o).all() and (host(st) == st_o).all()
+    e.close()
