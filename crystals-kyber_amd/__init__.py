@@ -28,11 +28,11 @@ ABI_SYMBOLS = (
     "mlkem_ctx_create", "mlkem_ctx_destroy", "mlkem_ctx_scratch_bytes", "mlkem_timing_begin", "mlkem_timing_end",
     "mlkem_keygen_dev", "mlkem_encaps_dev", "mlkem_decaps_dev",
     "mlkem_ntt_dev", "mlkem_intt_dev", "mlkem_multiply_ntts_dev", "mlkem_sample_ntt_dev", "mlkem_sample_cbd_dev",
-    "mlkem_prf_dev", "mlkem_hash_dev",
-    "mlkem_keygen", "mlkem_encaps", "mlkem_decaps", "mlkem_ntt", "mlkem_intt",
+    "mlkem_prf_dev", "mlkem_hash_dev", "mlkem_keccak_sponge_dev", "mlkem_sha3_pad_bits",
+    "mlkem_keygen", "mlkem_encaps", "mlkem_decaps", "mlkem_ntt", "mlkem_intt", "mlkem_keccak_sponge",
     "mlkem_keygen_random", "mlkem_encaps_random",
 )
-SHIM_SYMBOLS = ("init", "KEM_KeyGen", "KEM_Encaps", "KEM_Decaps", "ml_errno")
+SHIM_SYMBOLS = ("init", "KEM_KeyGen", "KEM_Encaps", "KEM_Decaps", "ml_errno", "sha3_b", "sha3_h", "sha3_s", "h2b", "b2h")
 
 
 class MLKEMError(RuntimeError):
@@ -83,6 +83,9 @@ def load_library():
     L.mlkem_keygen_random.argtypes = [i32, sz, vp, vp]
     L.mlkem_encaps_random.argtypes = [i32, sz, vp, C.c_uint, vp, vp]
     L.mlkem_timing_end.argtypes = [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int), i32]
+    L.mlkem_keccak_sponge_dev.argtypes = [vp, C.c_uint, sz, vp, C.c_uint, vp, C.c_uint, sz, vp]
+    L.mlkem_keccak_sponge.argtypes = [C.c_uint, sz, vp, C.c_uint, vp, C.c_uint]
+    L.mlkem_sha3_pad_bits.argtypes = [vp, sz, i32, C.c_uint, vp, sz]
     _lib = L
     return L
 
@@ -295,6 +298,28 @@ class MLKEM:
     def J(self, msgs):
         """J (ml_kem.c:540; SHAKE128 in the reference) -> [n,32]."""
         return self._hash(2, msgs, 32)
+
+    def sha3_bits(self, bits_list, xof, rate, outlen):
+        """SHA-3 / SHAKE of bit-granular messages (sha3_b, sha3.c:408): `bits_list` = equal-length sequences of 0/1;
+        suffix + pad10*1 on the host (mlkem_sha3_pad_bits), sponge on the device.  -> [n, outlen] bytes."""
+        import numpy as np
+        torch = self.torch
+        n = len(bits_list)
+        nbits = len(bits_list[0]) if n else 0
+        nblocks = (nbits + (4 if xof else 2) + 2 + 8 * rate - 1) // (8 * rate)
+        padded = np.zeros((n, nblocks * rate), np.uint8)
+        for i, b in enumerate(bits_list):
+            b = np.ascontiguousarray(b, np.uint8)
+            assert b.size == nbits
+            rc = self.lib.mlkem_sha3_pad_bits(b.ctypes.data, nbits, int(bool(xof)), rate, padded[i].ctypes.data, padded[i].size)
+            if rc != nblocks:
+                raise MLKEMError(rc, "sha3 padding failed")
+        dp = torch.from_numpy(padded).to(self.device)
+        stride = (outlen + 3) // 4 * 4
+        out = torch.zeros((n, stride), dtype=torch.uint8, device=self.device)
+        self._check(self.lib.mlkem_keccak_sponge_dev(self._ctx, rate, n, dp.data_ptr(), nblocks, out.data_ptr(), outlen, stride,
+                                                     self._stream()))
+        return out[:, :outlen]
 
     # NTT-only workload of BASELINE config 2
     NTT = ntt

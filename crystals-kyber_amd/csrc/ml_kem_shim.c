@@ -143,3 +143,82 @@ union byte* KEM_Decaps(const struct PARAMS* params, const union byte* dk, unsign
     free(pdk); free(pc);
     return result;
 }
+
+/* ------------------------------------------------------------------------------------------------------------
+ * sha3.h front-ends: same signatures, cell types and ownership as sha3.c:329-494.  Bit fiddling
+ * (hex <-> bits, suffix, pad10*1) happens here on the host; the sponge itself runs on the GPU through
+ * mlkem_keccak_sponge (a batch of one).  Failures (unsupported capacity, no device) print a message and return NULL.
+ * ---------------------------------------------------------------------------------------------------------- */
+union bit* h2b(const union hex* H, unsigned int m, unsigned int n) {   /* sha3.c:329-359 */
+    unsigned int total = 8 * m, keep = n < total ? n : total;
+    union bit* S = (union bit*)calloc(keep ? keep : 1, sizeof(union bit));
+    if (!S) return NULL;
+    for (unsigned int i = 0; i < keep; i++) {
+        unsigned int byte = 16 * H[2 * (i / 8)].d + H[2 * (i / 8) + 1].d;
+        S[i].b = (byte >> (i % 8)) & 1u;
+    }
+    return S;
+}
+
+union hex* b2h(const union bit* S, unsigned int n) {   /* sha3.c:367-396 */
+    unsigned int m = (n + 7) / 8;
+    union hex* H = (union hex*)calloc(2 * m ? 2 * m : 1, sizeof(union hex));
+    if (!H) return NULL;
+    for (unsigned int i = 0; i < m; i++) {
+        unsigned int byte = 0;
+        for (unsigned int j = 0; j < 8; j++)
+            if (8 * i + j < n) byte |= (S[8 * i + j].b & 1u) << j;
+        H[2 * i].d = (byte >> 4) & 15u;
+        H[2 * i + 1].d = byte & 15u;
+    }
+    return H;
+}
+
+union bit* sha3_b(const union bit* bstr, unsigned int n, unsigned int d, unsigned int c, union bit sfx[4]) {   /* sha3.c:408-436 */
+    if (c >= 1600 || ((1600 - c) % 8) != 0) { report("ml_kem shim - sha3_b()", "unsupported capacity"); return NULL; }
+    const unsigned rate = (1600 - c) / 8;
+    const int xof = sfx[2].b == 1;   /* sha3.c:414: four suffix bits 1111 for the XOFs, two bits 01 otherwise */
+    const size_t cap = ((size_t)n + 6 + 8 * rate) / (8 * rate) * rate + rate;
+    unsigned char* bits = (unsigned char*)malloc(n ? n : 1);
+    unsigned char* padded = (unsigned char*)malloc(cap);
+    unsigned char* out = (unsigned char*)malloc((d + 7) / 8 + 1);
+    union bit* D = NULL;
+    if (bits && padded && out) {
+        for (unsigned int i = 0; i < n; i++) bits[i] = (unsigned char)(bstr[i].b & 1u);
+        int nblocks = mlkem_sha3_pad_bits(bits, n, xof, rate, padded, cap);
+        int rc = nblocks > 0 ? mlkem_keccak_sponge(rate, 1, padded, (unsigned)nblocks, out, (d + 7) / 8) : nblocks;
+        if (!engine_failed("ml_kem shim - sha3_b()", rc)) {
+            D = (union bit*)calloc(d ? d : 1, sizeof(union bit));
+            if (D) for (unsigned int i = 0; i < d; i++) D[i].b = (out[i / 8] >> (i % 8)) & 1u;
+        }
+    }
+    free(bits); free(padded); free(out);
+    return D;
+}
+
+union hex* sha3_h(const union hex* hstr, unsigned int m, unsigned int d, unsigned int c, union bit sfx[4]) {   /* sha3.c:443-457 */
+    union bit* N = h2b(hstr, m, 8 * m);
+    if (!N) return NULL;
+    union bit* M = sha3_b(N, 8 * m, d, c, sfx);
+    free(N);
+    if (!M) return NULL;
+    union hex* D = b2h(M, d);
+    free(M);
+    return D;
+}
+
+unsigned char* sha3_s(const char* cstr, unsigned int m, unsigned int d, unsigned int c, union bit sfx[4]) {   /* sha3.c:465-494 */
+    union hex* H = (union hex*)calloc(2 * m ? 2 * m : 1, sizeof(union hex));
+    if (!H) return NULL;
+    for (unsigned int i = 0; i < m; i++) {
+        H[2 * i].d = ((unsigned char)cstr[i] >> 4) & 15u;
+        H[2 * i + 1].d = (unsigned char)cstr[i] & 15u;
+    }
+    union hex* Z = sha3_h(H, m, d, c, sfx);
+    free(H);
+    if (!Z) return NULL;
+    unsigned char* D = (unsigned char*)malloc(d / 8 ? d / 8 : 1);
+    if (D) for (unsigned int i = 0; i < d / 8; i++) D[i] = (unsigned char)((Z[2 * i].d << 4) ^ Z[2 * i + 1].d);
+    free(Z);
+    return D;
+}

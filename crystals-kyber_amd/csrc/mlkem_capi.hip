@@ -285,6 +285,32 @@ int mlkem_hash_dev(mlkem_ctx* ctx, int kind, size_t n, const uint8_t* msg, unsig
     HIP_TRY(hipGetLastError());
     return MLKEM_OK;
 }
+int mlkem_keccak_sponge_dev(mlkem_ctx* ctx, unsigned rate, size_t n, const uint8_t* padded, unsigned nblocks, uint8_t* out,
+                            unsigned outlen, size_t out_stride, void* stream) {
+    if (!ctx || (n && (!padded || !out)) || !aligned16(padded) || !aligned16(out)) return MLKEM_ERR_ARG;
+    if (n && sponge_raw_launch(static_cast<hipStream_t>(stream), rate, n, padded, nblocks, out, outlen, out_stride)) return MLKEM_ERR_ARG;
+    HIP_TRY(hipGetLastError());
+    return MLKEM_OK;
+}
+
+// Pure host helper (no device work): message bits (one per byte) + SHA-3 suffix + pad10*1 -> whole rate blocks.
+// sha3.c:408-436 (suffix "01" / "1111") and :226-240 (pad), without the reference's latent bug for
+// (n + suffix + 2) == 0 mod r.  Returns the number of blocks, or a negative error.
+int mlkem_sha3_pad_bits(const uint8_t* msg_bits, size_t nbits, int xof, unsigned rate, uint8_t* padded, size_t padded_cap) {
+    if (rate == 0 || rate > 200 || (rate & 7)) return MLKEM_ERR_ARG;
+    const size_t sbits = xof ? 4 : 2, rbits = (size_t)rate * 8;
+    const size_t nblocks = (nbits + sbits + 2 + rbits - 1) / rbits;
+    if (nblocks * rate > padded_cap || !padded || (nbits && !msg_bits)) return MLKEM_ERR_ARG;
+    memset(padded, 0, nblocks * rate);
+    auto setbit = [&](size_t pos) { padded[pos >> 3] |= (uint8_t)(1u << (pos & 7)); };
+    for (size_t i = 0; i < nbits; i++)
+        if (msg_bits[i] & 1) setbit(i);
+    if (xof) { setbit(nbits); setbit(nbits + 1); setbit(nbits + 2); setbit(nbits + 3); }
+    else setbit(nbits + 1);
+    setbit(nbits + sbits);               // first pad bit
+    setbit(nblocks * rbits - 1);         // last pad bit
+    return (int)nblocks;
+}
 
 }   // extern "C"
 
@@ -394,6 +420,25 @@ static int host_ntt(bool inverse, size_t n, const uint16_t* in, uint16_t* out) {
 }
 int mlkem_ntt(size_t n, const uint16_t* f, uint16_t* fh) { return host_ntt(false, n, f, fh); }
 int mlkem_intt(size_t n, const uint16_t* fh, uint16_t* f) { return host_ntt(true, n, fh, f); }
+
+int mlkem_keccak_sponge(unsigned rate, size_t n, const uint8_t* padded, unsigned nblocks, uint8_t* out, unsigned outlen) {
+    if (n && (!padded || !out)) return MLKEM_ERR_ARG;
+    std::lock_guard<std::mutex> lock(g_host_mu);
+    mlkem_ctx* ctx;
+    int rc = host_ctx(&ctx);
+    if (rc) return rc;
+    if (n == 0) return MLKEM_OK;
+    const size_t in_bytes = n * (size_t)nblocks * rate, ostride = ((size_t)outlen + 3) & ~(size_t)3;
+    DevBuf bi, bo;
+    if ((rc = bi.alloc(in_bytes)) || (rc = bo.alloc(n * ostride))) return rc;
+    HIP_TRY(hipMemcpy(bi.p, padded, in_bytes, hipMemcpyHostToDevice));
+    rc = mlkem_keccak_sponge_dev(ctx, rate, n, bi.as<uint8_t>(), nblocks, bo.as<uint8_t>(), outlen, ostride, nullptr);
+    if (rc) return rc;
+    std::vector<uint8_t> tmp(n * ostride);
+    HIP_TRY(hipMemcpy(tmp.data(), bo.p, n * ostride, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < n; i++) memcpy(out + i * outlen, tmp.data() + i * ostride, outlen);
+    return MLKEM_OK;
+}
 
 // ---- randomised wrappers: KEM_KeyGen / KEM_Encaps semantics at batch scale (ml_kem.c:458-478, :1233, :1257) --
 static bool fill_random(uint8_t* p, size_t n) {

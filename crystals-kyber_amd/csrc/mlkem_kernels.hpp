@@ -323,6 +323,49 @@ __global__ void __launch_bounds__(WAVE) k_hash_batch(size_t n, int kind, const u
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// k_sponge_raw — the bare Keccak sponge (sha3.c:257-317) over n already-padded messages: absorb `nblocks` rate
+// blocks per lane, squeeze `outlen` bytes.  Suffix bits and pad10*1 are applied by the caller (bit-granular lengths:
+// the sha3.h front-ends in the drop-in shim).  Message i at msg + i*nblocks*RATE, output i at
+// out + i*out_stride (out_stride % 4 == 0).
+// ------------------------------------------------------------------------------------------------
+template <int RATE>
+__global__ void __launch_bounds__(WAVE) k_sponge_raw(size_t n, const uint8_t* __restrict__ msg, unsigned nblocks, uint8_t* __restrict__ out,
+                                                     unsigned outlen, size_t out_stride) {
+    __shared__ __attribute__((aligned(16))) uint2 stage[STAGE_QWORDS];
+    const size_t item0 = (size_t)blockIdx.x * WAVE, item = item0 + lane_id();
+    KeccakState s;
+    const unsigned total = nblocks * RATE;
+    MsgView mv{msg, total, total, msg, total, 0};
+    keccak_zero(s);
+    for (unsigned voff = 0; voff < total; voff += RATE) {
+        wave_absorb_block<RATE>(s, stage, mv, item0, n, voff);
+        keccak_f1600(s);
+    }
+    uint8_t* o = out + (item < n ? item : n - 1) * out_stride;
+    for (unsigned done = 0; done < outlen; done += RATE) {
+        if (done) keccak_f1600(s);
+        const unsigned take = outlen - done < (unsigned)RATE ? outlen - done : (unsigned)RATE;
+        if (item < n) {
+#define MLKEM_SQ(W)                                                                                         \
+            if constexpr (W < RATE / 4) {                                                                   \
+                if (4u * W + 4u <= take) *reinterpret_cast<uint32_t*>(o + done + 4 * W) = keccak_word<W>(s); \
+                else if (4u * W < take) {                                                                   \
+                    const uint32_t v = keccak_word<W>(s);                                                   \
+                    for (unsigned b = 0; 4u * W + b < take; b++) o[done + 4 * W + b] = (uint8_t)(v >> (8 * b)); \
+                }                                                                                           \
+            }
+            MLKEM_SQ(0) MLKEM_SQ(1) MLKEM_SQ(2) MLKEM_SQ(3) MLKEM_SQ(4) MLKEM_SQ(5) MLKEM_SQ(6) MLKEM_SQ(7)
+            MLKEM_SQ(8) MLKEM_SQ(9) MLKEM_SQ(10) MLKEM_SQ(11) MLKEM_SQ(12) MLKEM_SQ(13) MLKEM_SQ(14) MLKEM_SQ(15)
+            MLKEM_SQ(16) MLKEM_SQ(17) MLKEM_SQ(18) MLKEM_SQ(19) MLKEM_SQ(20) MLKEM_SQ(21) MLKEM_SQ(22) MLKEM_SQ(23)
+            MLKEM_SQ(24) MLKEM_SQ(25) MLKEM_SQ(26) MLKEM_SQ(27) MLKEM_SQ(28) MLKEM_SQ(29) MLKEM_SQ(30) MLKEM_SQ(31)
+            MLKEM_SQ(32) MLKEM_SQ(33) MLKEM_SQ(34) MLKEM_SQ(35) MLKEM_SQ(36) MLKEM_SQ(37) MLKEM_SQ(38) MLKEM_SQ(39)
+            MLKEM_SQ(40) MLKEM_SQ(41)
+#undef MLKEM_SQ
+        }
+    }
+}
+
 // ================================================================================================
 // k_sample — lane-sliced SHAKE128 sponges.
 //   blocks [0, xof_blocks)            : XOF role, sponge g = block*64 + lane  -> SampleNTT (ml_kem.c:189-245)

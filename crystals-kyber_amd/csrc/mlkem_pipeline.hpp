@@ -337,4 +337,20 @@ inline int hash_launch(stream_t st, int kind, size_t n, const uint8_t* msg, unsi
     return 0;
 }
 
+// bare sponge over pre-padded messages (sha3.h front-ends); rate in bytes: 72 / 104 / 136 / 144 / 168
+inline int sponge_raw_launch(stream_t st, unsigned rate, size_t n, const uint8_t* msg, unsigned nblocks, uint8_t* out, unsigned outlen,
+                             size_t out_stride) {
+    if (nblocks == 0 || (out_stride & 3) || out_stride < outlen) return -1;
+    const size_t grid = ceil_div(n, WAVE);
+    switch (rate) {
+    case 72: launch("k_sponge_raw", k_sponge_raw<72>, grid, WAVE, st, n, msg, nblocks, out, outlen, out_stride); break;
+    case 104: launch("k_sponge_raw", k_sponge_raw<104>, grid, WAVE, st, n, msg, nblocks, out, outlen, out_stride); break;
+    case 136: launch("k_sponge_raw", k_sponge_raw<136>, grid, WAVE, st, n, msg, nblocks, out, outlen, out_stride); break;
+    case 144: launch("k_sponge_raw", k_sponge_raw<144>, grid, WAVE, st, n, msg, nblocks, out, outlen, out_stride); break;
+    case 168: launch("k_sponge_raw", k_sponge_raw<168>, grid, WAVE, st, n, msg, nblocks, out, outlen, out_stride); break;
+    default: return -1;
+    }
+    return 0;
+}
+
 }   // namespace mlkem

@@ -100,12 +100,22 @@ int mlkem_prf_dev(mlkem_ctx* ctx, int eta, size_t n, const uint8_t* in33, uint8_
  * msg + i*stride (stride % 8 == 0, stride >= len).  kind: 0 = H (32 B out), 1 = G (64 B), 2 = J (32 B, SHAKE128) */
 int mlkem_hash_dev(mlkem_ctx* ctx, int kind, size_t n, const uint8_t* msg, unsigned len, size_t stride, uint8_t* out, void* stream);
 
+/* replaces Sponge[Keccak-f[1600], pad10*1, r] sha3.c:257-317 on n PRE-PADDED messages of `nblocks` rate blocks each
+ * (rate in bytes: 72 / 104 / 136 / 144 / 168), `outlen` bytes squeezed per message into rows of `out_stride`
+ * (out_stride % 4 == 0).  Used by the sha3.h front-ends of the drop-in shim (sha3_b / sha3_h / sha3_s). */
+int mlkem_keccak_sponge_dev(mlkem_ctx* ctx, unsigned rate, size_t n, const uint8_t* padded, unsigned nblocks, uint8_t* out,
+                            unsigned outlen, size_t out_stride, void* stream);
+/* host helper, no device work: message bits (one per byte) + suffix ("01" hash / "1111" XOF: sha3.c:408-436) + pad10*1
+ * (sha3.c:226-240) -> whole rate blocks in `padded`; returns the number of blocks or a negative error */
+int mlkem_sha3_pad_bits(const uint8_t* msg_bits, size_t nbits, int xof, unsigned rate, uint8_t* padded, size_t padded_cap);
+
 /* ---- batched KEM, host pointers (stage + run + synchronise) ---------------------------------------- */
 int mlkem_keygen(int param_set, size_t n, const uint8_t* d, const uint8_t* z, uint8_t* ek, uint8_t* dk);
 int mlkem_encaps(int param_set, size_t n, const uint8_t* ek, const uint8_t* m, uint8_t* c, uint8_t* K);
 int mlkem_decaps(int param_set, size_t n, const uint8_t* dk, const uint8_t* c, uint8_t* K, int32_t* status);
 int mlkem_ntt(size_t n, const uint16_t* f, uint16_t* f_hat);
 int mlkem_intt(size_t n, const uint16_t* f_hat, uint16_t* f);
+int mlkem_keccak_sponge(unsigned rate, size_t n, const uint8_t* padded, unsigned nblocks, uint8_t* out, unsigned outlen);
 
 /* ---- randomised wrappers: seeds drawn on the host with getrandom(2) ---------------- */
 /* replaces KEM_KeyGen(params)  ml_kem.c:1233-1252 for n key pairs */

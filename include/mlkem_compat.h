@@ -51,6 +51,28 @@ struct KEM {
 enum ML_KEM { ML_KEM_512 = 512, ML_KEM_768 = 768, ML_KEM_1024 = 1024 };
 
 const struct PARAMS init(enum ML_KEM param_set);
+
+/* ---- sha3.h surface re-exported through ml_kem.h:10 --------------------------------------------
+ *   symbol   reference declaration   replaced definition
+ *   h2b      sha3.h:28               sha3.c:329-359
+ *   b2h      sha3.h:35               sha3.c:367-396
+ *   sha3_b   sha3.h:44               sha3.c:408-436 (+ Sponge :257, pad :226, Keccak_f :207)
+ *   sha3_h   sha3.h:54               sha3.c:443-457
+ *   sha3_s   sha3.h:64               sha3.c:465-494
+ * `union bit` / `union hex` are 4-byte cells like `union byte`.  Every result is malloc()ed for the caller.
+ * Capacities c with rate (1600 - c)/8 in {72, 104, 136, 144, 168} bytes are supported (all SHA-3 / SHAKE
+ * instances); the reference's padding bug for bit lengths = r-2 mod r is NOT reproduced. */
+union bit {
+    unsigned int b : 1;
+};
+union hex {
+    unsigned int d : 4;
+};
+union bit* h2b(const union hex* H, unsigned int m, unsigned int n);
+union hex* b2h(const union bit* S, unsigned int n);
+union bit* sha3_b(const union bit* bstr, unsigned int n, unsigned int d, unsigned int c, union bit sfx[4]);
+union hex* sha3_h(const union hex* hstr, unsigned int m, unsigned int d, unsigned int c, union bit sfx[4]);
+unsigned char* sha3_s(const char* cstr, unsigned int m, unsigned int d, unsigned int c, union bit sfx[4]);
 struct PKE KEM_KeyGen(const struct PARAMS* params);
 struct KEM KEM_Encaps(const struct PARAMS* params, const union byte* ek, unsigned int ek_len);
 union byte* KEM_Decaps(const struct PARAMS* params, const union byte* dk, unsigned int dk_len, const union byte* c,

@@ -66,6 +66,9 @@ int emu_prf(int eta, size_t n, const uint8_t* in33, uint8_t* out) { return prf_l
 int emu_hash(int kind, size_t n, const uint8_t* msg, unsigned len, size_t stride, uint8_t* out) {
     return hash_launch(nullptr, kind, n, msg, len, stride, out);
 }
+int emu_sponge_raw(unsigned rate, size_t n, const uint8_t* msg, unsigned nblocks, uint8_t* out, unsigned outlen, size_t out_stride) {
+    return sponge_raw_launch(nullptr, rate, n, msg, nblocks, out, outlen, out_stride);
+}
 // SampleNTT of a k x k matrix through the production path (three-block main kernel + leftover pass);
 // returns the number of sponges that went through the leftover list.
 int emu_sample_matrix(int k, size_t n, const uint8_t* rho, int transpose, uint16_t* A_out) {

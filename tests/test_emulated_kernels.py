@@ -145,3 +145,32 @@ def test_emu_chunk_and_hchunk_loops(emu, oracle):
         assert (st == 0).all() and (sto == 0).all() and (Kd == Ko).all()
     finally:
         emu.emu_config(C.c_size_t(0), C.c_size_t(0), 64)
+
+
+def test_emu_raw_sponge_nist_examples_and_bit_lengths(emu, oracle, golden):
+    """the bare sponge kernel + the host padding helper (mlkem_sha3_pad_bits in libmlkem_amd.so,
+    a pure host function) against the 16 NIST FIPS-202 examples the reference ships, incl. 5/30/1605/1630-bit messages."""
+    lib = ge.load_package().load_library()
+    for ex in golden["G8_nist_sha3"]:
+        bits = np.array([int(ch) for ch in ex["msg_bits"]], np.uint8)
+        rate, want = ex["rate_bytes"], bytes.fromhex(ex["out"])
+        padded = np.zeros(((bits.size + 6) // (8 * rate) + 2) * rate, np.uint8)
+        nb = lib.mlkem_sha3_pad_bits(bits.ctypes.data, bits.size, int(ex["xof"]), rate, padded.ctypes.data, padded.size)
+        assert nb > 0
+        n = 3   # same message in three lanes
+        msgs = np.tile(padded[: nb * rate], (n, 1))
+        stride = (len(want) + 3) // 4 * 4
+        out = np.zeros((n, stride), np.uint8)
+        assert emu.emu_sponge_raw(rate, C.c_size_t(n), p8(msgs), nb, p8(out), len(want), C.c_size_t(stride)) == 0
+        assert bytes(out[2, : len(want)]) == want, ex["file"]
+    rng = np.random.default_rng(8)
+    for rate, xof in ((136, False), (168, True), (72, False), (104, False), (144, False), (136, True)):
+        for nbits in (0, 1, 7, 8 * rate - 3, 8 * rate - 2, 8 * rate - 1, 8 * rate, 8 * rate + 1, 2501):
+            bits = rng.integers(0, 2, nbits).astype(np.uint8)
+            padded = np.zeros((nbits // (8 * rate) + 2) * rate, np.uint8)
+            nb = lib.mlkem_sha3_pad_bits(bits.ctypes.data, nbits, int(xof), rate, padded.ctypes.data, padded.size)
+            outlen = 200 if xof else 32
+            out = np.zeros((1, outlen), np.uint8)
+            m1 = padded[: nb * rate][None].copy()
+            assert emu.emu_sponge_raw(rate, C.c_size_t(1), p8(m1), nb, p8(out), outlen, C.c_size_t(outlen)) == 0
+            assert (out[0] == oracle.sponge_bits(rate, xof, bits, outlen)).all(), (rate, xof, nbits)

@@ -367,3 +367,53 @@ def test_engine_options_do_not_change_results(pkg, torch, oracle, env, monkeypat
     assert (host(ek) == ek_o).all() and (host(dk) == dk_o).all() and (host(c) == c_o).all() and (host(K) == K_o).all()
     assert (host(Kd) == Kd_o).all() and (host(st) == st_o).all()
     e.close()
+
+
+def test_sha3_surface_nist_examples(pkg, engines, torch, golden):
+    """SURVEY 8f row 2 on the GPU: (1) the batched sponge through the Python binding, (2) the reference-ABI front-ends
+    sha3_b / sha3_h / sha3_s / h2b / b2h of the drop-in shim (4-byte cells), against the NIST examples."""
+    import hashlib
+    e = engines[768]
+    for ex in golden["G8_nist_sha3"]:
+        bits = [int(ch) for ch in ex["msg_bits"]]
+        want = bytes.fromhex(ex["out"])
+        got = host(e.sha3_bits([bits, bits], ex["xof"], ex["rate_bytes"], len(want)))
+        assert bytes(got[1]) == want, ex["file"]
+    shim = C.CDLL(pkg.SHIM_PATH)
+    libc = C.CDLL(None)
+    libc.free.argtypes = [C.c_void_p]
+    cell = C.c_uint
+    shim.sha3_b.restype = C.POINTER(cell)
+    shim.sha3_b.argtypes = [C.POINTER(cell), C.c_uint, C.c_uint, C.c_uint, C.POINTER(cell)]
+    sfx_hash, sfx_xof = (cell * 4)(0, 1, 0, 0), (cell * 4)(1, 1, 1, 1)
+    for ex in golden["G8_nist_sha3"]:
+        bits = [int(ch) for ch in ex["msg_bits"]]
+        want = bytes.fromhex(ex["out"])
+        cells = (cell * max(1, len(bits)))(*[b | 0xABCD0000 for b in bits])   # garbage above bit 0 must be ignored
+        cap = 1600 - 8 * ex["rate_bytes"]
+        r = shim.sha3_b(cells, len(bits), 8 * len(want), cap, sfx_xof if ex["xof"] else sfx_hash)
+        assert r, ex["file"]
+        got = np.packbits(np.array([r[i] & 1 for i in range(8 * len(want))], np.uint8), bitorder="little")
+        libc.free(r)
+        assert bytes(got) == want, ex["file"]
+    # character front-end (sha3_s) and the hex helpers
+    shim.sha3_s.restype = C.POINTER(C.c_ubyte)
+    shim.sha3_s.argtypes = [C.c_char_p, C.c_uint, C.c_uint, C.c_uint, C.POINTER(cell)]
+    msg = b"MI355X batched ML-KEM"
+    r = shim.sha3_s(msg, len(msg), 256, 512, sfx_hash)
+    assert bytes(r[i] for i in range(32)) == hashlib.sha3_256(msg).digest()
+    libc.free(r)
+    r = shim.sha3_s(msg, len(msg), 8 * 200, 256, sfx_xof)
+    assert bytes(r[i] for i in range(200)) == hashlib.shake_128(msg).digest(200)
+    libc.free(r)
+    shim.h2b.restype = C.POINTER(cell)
+    shim.h2b.argtypes = [C.POINTER(cell), C.c_uint, C.c_uint]
+    shim.b2h.restype = C.POINTER(cell)
+    shim.b2h.argtypes = [C.POINTER(cell), C.c_uint]
+    hx = (cell * 4)(0xA, 0x3, 0x0, 0xF)          # bytes A3 0F
+    b = shim.h2b(hx, 2, 13)
+    assert [b[i] & 1 for i in range(13)] == [1, 1, 0, 0, 0, 1, 0, 1, 1, 1, 1, 1, 0]   # LSB-first within each byte
+    h = shim.b2h(b, 13)
+    assert [h[i] & 15 for i in range(4)] == [0xA, 0x3, 0x0, 0xF]
+    libc.free(b)
+    libc.free(h)
