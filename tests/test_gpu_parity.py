@@ -417,3 +417,30 @@ def test_sha3_surface_nist_examples(pkg, engines, torch, golden):
     assert [h[i] & 15 for i in range(4)] == [0xA, 0x3, 0x0, 0xF]
     libc.free(b)
     libc.free(h)
+
+
+def test_dev_calls_are_graph_capturable(pkg, torch, oracle):
+    """The *_dev entry points neither allocate nor synchronise: a whole encaps+decaps pass is captured into a HIP graph
+    on a side stream and replayed on new inputs."""
+    e = pkg.MLKEM(768, device=0, chunk_items=64)
+    n = 200
+    d, z = seeds("graph-d", n, 1), seeds("graph-z", n, 1)
+    ek, dk = e.keygen(dev(torch, d), dev(torch, z))
+    m = dev(torch, seeds("graph-m", n, 1))
+    c = torch.empty((n, 1088), dtype=torch.uint8, device="cuda")
+    K = torch.empty((n, 32), dtype=torch.uint8, device="cuda")
+    K2 = torch.empty((n, 32), dtype=torch.uint8, device="cuda")
+    st = torch.empty(n, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        e.encaps(ek, m, c=c, K=K)
+        e.decaps(dk, c, K=K2, status=st)
+    m2 = seeds("graph-m2", n, 2)
+    m.copy_(dev(torch, m2))
+    c.zero_(); K.zero_(); K2.zero_(); st.fill_(7)
+    g.replay()
+    torch.cuda.synchronize()
+    c_o, K_o = oracle.encaps(768, host(ek), m2)
+    assert (host(c) == c_o).all() and (host(K) == K_o).all() and (host(K2) == K_o).all() and (host(st) == 0).all()
+    e.close()
