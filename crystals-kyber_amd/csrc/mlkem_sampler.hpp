@@ -68,10 +68,32 @@ __device__ __forceinline__ void ring_flush_t(const int16_t* ring, uint16_t* A, s
         if (FIRST <= 2 && LAST > 2) T((w1 >> 16) | ((w2 & 0xFFu) << 16))                                  \
         if (FIRST <= 3 && LAST > 3) T(w2 >> 8)                                                            \
     }
+// Own-lane flush: every lane copies its own completed chunk (CHUNK/8 x ds_read_b128 + global_store_dwordx4).  No
+// cross-lane traffic, no fences; the scattered 16-byte stores (one 64-byte segment per lane, completed by consecutive
+// instructions) ride on the otherwise idle memory pipe, whereas the cooperative variant above spends ~45 VALU/DS
+// instructions per flush point in a VALU-bound kernel.  MLKEM_SAMPLER_COOP_FLUSH=1 selects the cooperative variant.
+#ifndef MLKEM_SAMPLER_COOP_FLUSH
+#define MLKEM_SAMPLER_COOP_FLUSH 0
+#endif
+template <class R>
+__device__ __forceinline__ void ring_flush_own(const int16_t* myring, uint16_t* A, size_t g, size_t n_xof, int cnt, int& flushed) {
+    if ((cnt - flushed >= R::CHUNK) && (g < n_xof)) {
+        const int16_t* src = myring + (flushed & (R::N - 1));
+        uint16_t* dst = A + g * 256 + flushed;
+#pragma unroll
+        for (int q = 0; q < R::CHUNK / 8; q++)
+            reinterpret_cast<uint4*>(dst)[q] = reinterpret_cast<const uint4*>(src)[q];
+        flushed += R::CHUNK;
+    }
+}
+#if MLKEM_SAMPLER_COOP_FLUSH
 #define MLKEM_FLUSH()                                               \
     wave_lds_fence();                                               \
     ring_flush_t<R>(ring, a.A, g, a.n_xof, cnt, flushed);           \
     wave_lds_fence();
+#else
+#define MLKEM_FLUSH() ring_flush_own<R>(myring, a.A, g, a.n_xof, cnt, flushed);
+#endif
 
 // the 56 triples of one squeezed block, with NFLUSH = 4 (quarters of 14 triples) or 2 (halves of 28) flush points
 #define MLKEM_BLOCK(T)                                                                                      \
