@@ -31,6 +31,7 @@ ABI_SYMBOLS = (
     "mlkem_prf_dev", "mlkem_hash_dev", "mlkem_keccak_sponge_dev", "mlkem_sha3_pad_bits",
     "mlkem_keygen", "mlkem_encaps", "mlkem_decaps", "mlkem_ntt", "mlkem_intt", "mlkem_keccak_sponge",
     "mlkem_keygen_random", "mlkem_encaps_random",
+    "mlkem_cells_to_bytes_dev", "mlkem_bytes_to_cells_dev", "mlkem_keygen_stream", "mlkem_encaps_stream", "mlkem_decaps_stream",
 )
 SHIM_SYMBOLS = ("init", "KEM_KeyGen", "KEM_Encaps", "KEM_Decaps", "ml_errno", "sha3_b", "sha3_h", "sha3_s", "h2b", "b2h")
 
@@ -86,6 +87,11 @@ def load_library():
     L.mlkem_keccak_sponge_dev.argtypes = [vp, C.c_uint, sz, vp, C.c_uint, vp, C.c_uint, sz, vp]
     L.mlkem_keccak_sponge.argtypes = [C.c_uint, sz, vp, C.c_uint, vp, C.c_uint]
     L.mlkem_sha3_pad_bits.argtypes = [vp, sz, i32, C.c_uint, vp, sz]
+    L.mlkem_cells_to_bytes_dev.argtypes = [vp, sz, vp, vp, vp]
+    L.mlkem_bytes_to_cells_dev.argtypes = [vp, sz, vp, vp, vp]
+    L.mlkem_keygen_stream.argtypes = [i32, sz, vp, vp, vp, vp, sz]
+    L.mlkem_encaps_stream.argtypes = [i32, sz, vp, vp, vp, vp, sz]
+    L.mlkem_decaps_stream.argtypes = [i32, sz, vp, vp, vp, vp, sz]
     _lib = L
     return L
 
@@ -298,6 +304,21 @@ class MLKEM:
     def J(self, msgs):
         """J (ml_kem.c:540; SHAKE128 in the reference) -> [n,32]."""
         return self._hash(2, msgs, 32)
+
+    def cells_to_bytes(self, cells):
+        """`union byte` cells (int32 storage, value in bits 0-7) -> packed uint8, on the device."""
+        torch = self.torch
+        cells = cells.to(device=self.device).contiguous().view(torch.int32)
+        out = torch.empty(cells.numel(), dtype=torch.uint8, device=self.device)
+        self._check(self.lib.mlkem_cells_to_bytes_dev(self._ctx, cells.numel(), cells.data_ptr(), out.data_ptr(), self._stream()))
+        return out.reshape(cells.shape)
+
+    def bytes_to_cells(self, data):
+        torch = self.torch
+        data = data.to(device=self.device, dtype=torch.uint8).contiguous()
+        out = torch.empty(data.numel(), dtype=torch.int32, device=self.device)
+        self._check(self.lib.mlkem_bytes_to_cells_dev(self._ctx, data.numel(), data.data_ptr(), out.data_ptr(), self._stream()))
+        return out.reshape(data.shape)
 
     def sha3_bits(self, bits_list, xof, rate, outlen):
         """SHA-3 / SHAKE of bit-granular messages (sha3_b, sha3.c:408): `bits_list` = equal-length sequences of 0/1;

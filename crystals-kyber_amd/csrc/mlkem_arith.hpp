@@ -433,4 +433,39 @@ __global__ void __launch_bounds__(WAVE * ARITH_WAVES) k_cbd_batch(size_t n, cons
     }
 }
 
+// ================================================================================================
+// layout converters: the reference keeps every "byte" in a 4-byte `union byte` cell (value in bits
+// 0-7, upper 24 bits undefined: ml_kem.h:35-38).  Pure streaming kernels, 16 cells (64 B in / 16 B out, or
+// the reverse) per lane and iteration; the n % 16 tail is handled cell by cell.
+// ================================================================================================
+__global__ void __launch_bounds__(256) k_cells_to_bytes(size_t n, const uint32_t* __restrict__ cells, uint8_t* __restrict__ bytes) {
+    const size_t groups = n / 16, stride = (size_t)gridDim.x * blockDim.x;
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (size_t g = t; g < groups; g += stride) {
+        const uint4* src = reinterpret_cast<const uint4*>(cells) + 4 * g;
+        const uint4 a = src[0], b = src[1], c = src[2], d = src[3];
+        uint4 o;
+        o.x = (a.x & 0xFFu) | ((a.y & 0xFFu) << 8) | ((a.z & 0xFFu) << 16) | (a.w << 24);
+        o.y = (b.x & 0xFFu) | ((b.y & 0xFFu) << 8) | ((b.z & 0xFFu) << 16) | (b.w << 24);
+        o.z = (c.x & 0xFFu) | ((c.y & 0xFFu) << 8) | ((c.z & 0xFFu) << 16) | (c.w << 24);
+        o.w = (d.x & 0xFFu) | ((d.y & 0xFFu) << 8) | ((d.z & 0xFFu) << 16) | (d.w << 24);
+        reinterpret_cast<uint4*>(bytes)[g] = o;
+    }
+    for (size_t i = groups * 16 + t; i < n; i += stride) bytes[i] = (uint8_t)cells[i];
+}
+__global__ void __launch_bounds__(256) k_bytes_to_cells(size_t n, const uint8_t* __restrict__ bytes, uint32_t* __restrict__ cells) {
+    const size_t groups = n / 16, stride = (size_t)gridDim.x * blockDim.x;
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (size_t g = t; g < groups; g += stride) {
+        const uint4 v = reinterpret_cast<const uint4*>(bytes)[g];
+        uint4* dst = reinterpret_cast<uint4*>(cells) + 4 * g;
+        uint4 o;
+        o.x = v.x & 0xFFu; o.y = (v.x >> 8) & 0xFFu; o.z = (v.x >> 16) & 0xFFu; o.w = v.x >> 24; dst[0] = o;
+        o.x = v.y & 0xFFu; o.y = (v.y >> 8) & 0xFFu; o.z = (v.y >> 16) & 0xFFu; o.w = v.y >> 24; dst[1] = o;
+        o.x = v.z & 0xFFu; o.y = (v.z >> 8) & 0xFFu; o.z = (v.z >> 16) & 0xFFu; o.w = v.z >> 24; dst[2] = o;
+        o.x = v.w & 0xFFu; o.y = (v.w >> 8) & 0xFFu; o.z = (v.w >> 16) & 0xFFu; o.w = v.w >> 24; dst[3] = o;
+    }
+    for (size_t i = groups * 16 + t; i < n; i += stride) cells[i] = bytes[i];
+}
+
 }   // namespace mlkem

@@ -293,6 +293,19 @@ int mlkem_keccak_sponge_dev(mlkem_ctx* ctx, unsigned rate, size_t n, const uint8
     return MLKEM_OK;
 }
 
+int mlkem_cells_to_bytes_dev(mlkem_ctx* ctx, size_t n, const uint32_t* cells, uint8_t* bytes, void* stream) {
+    if (!ctx || (n && (!cells || !bytes)) || !aligned16(cells) || !aligned16(bytes)) return MLKEM_ERR_ARG;
+    if (n) cells_launch(static_cast<hipStream_t>(stream), true, n, cells, bytes);
+    HIP_TRY(hipGetLastError());
+    return MLKEM_OK;
+}
+int mlkem_bytes_to_cells_dev(mlkem_ctx* ctx, size_t n, const uint8_t* bytes, uint32_t* cells, void* stream) {
+    if (!ctx || (n && (!cells || !bytes)) || !aligned16(cells) || !aligned16(bytes)) return MLKEM_ERR_ARG;
+    if (n) cells_launch(static_cast<hipStream_t>(stream), false, n, bytes, cells);
+    HIP_TRY(hipGetLastError());
+    return MLKEM_OK;
+}
+
 // Pure host helper (no device work): message bits (one per byte) + SHA-3 suffix + pad10*1 -> whole rate blocks.
 // sha3.c:408-436 (suffix "01" / "1111") and :226-240 (pad), without the reference's latent bug for
 // (n + suffix + 2) == 0 mod r.  Returns the number of blocks, or a negative error.
@@ -438,6 +451,115 @@ int mlkem_keccak_sponge(unsigned rate, size_t n, const uint8_t* padded, unsigned
     HIP_TRY(hipMemcpy(tmp.data(), bo.p, n * ostride, hipMemcpyDeviceToHost));
     for (size_t i = 0; i < n; i++) memcpy(out + i * outlen, tmp.data() + i * ostride, outlen);
     return MLKEM_OK;
+}
+
+}   // extern "C"
+
+// ---- streaming front-end for HOST-resident batches ---------------------------------------------
+// Two slots, each with its own stream, engine context, device buffers and PINNED staging buffers.  Chunk i uses slot
+// i & 1: while slot A's H2D copy / kernels / D2H copy run, the host drains slot B's previous outputs into the caller's
+// memory and fills its staging buffers with the next inputs.  The rate is bounded by PCIe.
+namespace {
+
+struct Span { const void* in; void* out; size_t bytes; };   // per-item bytes; exactly one of in/out is set
+
+struct StreamSlot {
+    hipStream_t st = nullptr;
+    mlkem_ctx* ctx = nullptr;
+    std::vector<void*> dev, pin;
+    size_t pending = 0, pending_off = 0;   // items whose outputs still sit in the pinned buffers
+};
+
+template <class Launch>
+int stream_op(size_t n, size_t chunk, const std::vector<Span>& spans, Launch launch) {
+    if (n == 0) return MLKEM_OK;
+    if (chunk == 0) chunk = (size_t)1 << 16;
+    if (chunk > n) chunk = n;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return MLKEM_ERR_NO_DEVICE;
+    StreamSlot slot[2];
+    int rc = MLKEM_OK;
+    auto cleanup = [&]() {
+        for (auto& s : slot) {
+            if (s.st) (void)hipStreamSynchronize(s.st);
+            for (void* p : s.dev) if (p) (void)hipFree(p);
+            for (void* p : s.pin) if (p) (void)hipHostFree(p);
+            if (s.ctx) mlkem_ctx_destroy(s.ctx);
+            if (s.st) (void)hipStreamDestroy(s.st);
+        }
+    };
+    const int nslots = n > chunk ? 2 : 1;
+    for (int k = 0; k < nslots && rc == MLKEM_OK; k++) {
+        StreamSlot& s = slot[k];
+        if (!hip_ok(hipStreamCreateWithFlags(&s.st, hipStreamNonBlocking), "hipStreamCreate")) { rc = MLKEM_ERR_NO_DEVICE; break; }
+        rc = mlkem_ctx_create(&s.ctx, dev, chunk);
+        for (const Span& sp : spans) {
+            void *d = nullptr, *p = nullptr;
+            if (rc == MLKEM_OK && !hip_ok(hipMalloc(&d, chunk * sp.bytes), "hipMalloc")) rc = MLKEM_ERR_ALLOC;
+            if (rc == MLKEM_OK && !hip_ok(hipHostMalloc(&p, chunk * sp.bytes, hipHostMallocDefault), "hipHostMalloc")) rc = MLKEM_ERR_ALLOC;
+            s.dev.push_back(d);
+            s.pin.push_back(p);
+        }
+    }
+    auto drain = [&](StreamSlot& s) -> int {   // wait for the slot and hand its outputs to the caller
+        if (!s.pending) return MLKEM_OK;
+        if (!hip_ok(hipStreamSynchronize(s.st), "hipStreamSynchronize")) return MLKEM_ERR_NO_DEVICE;
+        for (size_t j = 0; j < spans.size(); j++)
+            if (spans[j].out) memcpy(static_cast<uint8_t*>(spans[j].out) + s.pending_off * spans[j].bytes, s.pin[j], s.pending * spans[j].bytes);
+        s.pending = 0;
+        return MLKEM_OK;
+    };
+    size_t i = 0;
+    for (size_t off = 0; off < n && rc == MLKEM_OK; off += chunk, i++) {
+        StreamSlot& s = slot[i % nslots];
+        const size_t cnt = n - off < chunk ? n - off : chunk;
+        if ((rc = drain(s)) != MLKEM_OK) break;
+        for (size_t j = 0; j < spans.size() && rc == MLKEM_OK; j++)
+            if (spans[j].in) {
+                memcpy(s.pin[j], static_cast<const uint8_t*>(spans[j].in) + off * spans[j].bytes, cnt * spans[j].bytes);
+                if (!hip_ok(hipMemcpyAsync(s.dev[j], s.pin[j], cnt * spans[j].bytes, hipMemcpyHostToDevice, s.st), "H2D")) rc = MLKEM_ERR_NO_DEVICE;
+            }
+        if (rc == MLKEM_OK) rc = launch(s.ctx, cnt, s.dev, s.st);
+        for (size_t j = 0; j < spans.size() && rc == MLKEM_OK; j++)
+            if (spans[j].out && !hip_ok(hipMemcpyAsync(s.pin[j], s.dev[j], cnt * spans[j].bytes, hipMemcpyDeviceToHost, s.st), "D2H")) rc = MLKEM_ERR_NO_DEVICE;
+        s.pending = cnt;
+        s.pending_off = off;
+    }
+    for (int k = 0; k < nslots && rc == MLKEM_OK; k++) rc = drain(slot[k]);
+    cleanup();
+    return rc;
+}
+
+}   // namespace
+
+extern "C" {
+
+int mlkem_keygen_stream(int set, size_t n, const uint8_t* d, const uint8_t* z, uint8_t* ek, uint8_t* dk, size_t chunk_items) {
+    ParamSet p;
+    if (!param_set(set, p)) return MLKEM_ERR_PARAM_SET;
+    if (n && (!d || !z || !ek || !dk)) return MLKEM_ERR_ARG;
+    std::vector<Span> sp = {{d, nullptr, 32}, {z, nullptr, 32}, {nullptr, ek, p.ek_len}, {nullptr, dk, p.dk_len}};
+    return stream_op(n, chunk_items, sp, [&](mlkem_ctx* ctx, size_t cnt, const std::vector<void*>& b, hipStream_t st) {
+        return mlkem_keygen_dev(ctx, set, cnt, (const uint8_t*)b[0], (const uint8_t*)b[1], (uint8_t*)b[2], (uint8_t*)b[3], st);
+    });
+}
+int mlkem_encaps_stream(int set, size_t n, const uint8_t* ek, const uint8_t* m, uint8_t* c, uint8_t* K, size_t chunk_items) {
+    ParamSet p;
+    if (!param_set(set, p)) return MLKEM_ERR_PARAM_SET;
+    if (n && (!ek || !m || !c || !K)) return MLKEM_ERR_ARG;
+    std::vector<Span> sp = {{ek, nullptr, p.ek_len}, {m, nullptr, 32}, {nullptr, c, p.c_len}, {nullptr, K, 32}};
+    return stream_op(n, chunk_items, sp, [&](mlkem_ctx* ctx, size_t cnt, const std::vector<void*>& b, hipStream_t st) {
+        return mlkem_encaps_dev(ctx, set, cnt, (const uint8_t*)b[0], (const uint8_t*)b[1], (uint8_t*)b[2], (uint8_t*)b[3], st);
+    });
+}
+int mlkem_decaps_stream(int set, size_t n, const uint8_t* dk, const uint8_t* c, uint8_t* K, int32_t* status, size_t chunk_items) {
+    ParamSet p;
+    if (!param_set(set, p)) return MLKEM_ERR_PARAM_SET;
+    if (n && (!dk || !c || !K || !status)) return MLKEM_ERR_ARG;
+    std::vector<Span> sp = {{dk, nullptr, p.dk_len}, {c, nullptr, p.c_len}, {nullptr, K, 32}, {nullptr, status, 4}};
+    return stream_op(n, chunk_items, sp, [&](mlkem_ctx* ctx, size_t cnt, const std::vector<void*>& b, hipStream_t st) {
+        return mlkem_decaps_dev(ctx, set, cnt, (const uint8_t*)b[0], (const uint8_t*)b[1], (uint8_t*)b[2], (int32_t*)b[3], st);
+    });
 }
 
 // ---- randomised wrappers: KEM_KeyGen / KEM_Encaps semantics at batch scale (ml_kem.c:458-478, :1233, :1257) --

@@ -337,6 +337,15 @@ inline int hash_launch(stream_t st, int kind, size_t n, const uint8_t* msg, unsi
     return 0;
 }
 
+// 4-byte `union byte` cells <-> packed bytes
+inline void cells_launch(stream_t st, bool to_bytes, size_t n, const void* in, void* out) {
+    size_t grid = ceil_div(ceil_div(n, 16), 256);
+    if (grid > 256 * 8) grid = 256 * 8;
+    if (grid == 0) grid = 1;
+    if (to_bytes) launch("k_cells_to_bytes", k_cells_to_bytes, grid, 256u, st, n, (const uint32_t*)in, (uint8_t*)out);
+    else launch("k_bytes_to_cells", k_bytes_to_cells, grid, 256u, st, n, (const uint8_t*)in, (uint32_t*)out);
+}
+
 // bare sponge over pre-padded messages (sha3.h front-ends); rate in bytes: 72 / 104 / 136 / 144 / 168
 inline int sponge_raw_launch(stream_t st, unsigned rate, size_t n, const uint8_t* msg, unsigned nblocks, uint8_t* out, unsigned outlen,
                              size_t out_stride) {

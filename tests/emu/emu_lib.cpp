@@ -66,6 +66,7 @@ int emu_prf(int eta, size_t n, const uint8_t* in33, uint8_t* out) { return prf_l
 int emu_hash(int kind, size_t n, const uint8_t* msg, unsigned len, size_t stride, uint8_t* out) {
     return hash_launch(nullptr, kind, n, msg, len, stride, out);
 }
+void emu_cells(int to_bytes, size_t n, const void* in, void* out) { cells_launch(nullptr, to_bytes != 0, n, in, out); }
 int emu_sponge_raw(unsigned rate, size_t n, const uint8_t* msg, unsigned nblocks, uint8_t* out, unsigned outlen, size_t out_stride) {
     return sponge_raw_launch(nullptr, rate, n, msg, nblocks, out, outlen, out_stride);
 }

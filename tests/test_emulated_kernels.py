@@ -174,3 +174,17 @@ def test_emu_raw_sponge_nist_examples_and_bit_lengths(emu, oracle, golden):
             m1 = padded[: nb * rate][None].copy()
             assert emu.emu_sponge_raw(rate, C.c_size_t(1), p8(m1), nb, p8(out), outlen, C.c_size_t(outlen)) == 0
             assert (out[0] == oracle.sponge_bits(rate, xof, bits, outlen)).all(), (rate, xof, nbits)
+
+
+def test_emu_cell_converters(emu):
+    """4-byte `union byte` cells <-> packed bytes; garbage in the upper 24 bits is ignored (F1)."""
+    rng = np.random.default_rng(4)
+    for n in (0, 1, 15, 16, 17, 1000, 4099):
+        b = rng.integers(0, 256, n).astype(np.uint8)
+        cells = b.astype(np.uint32) | (rng.integers(0, 1 << 24, n).astype(np.uint32) << 8)
+        out = np.full(n + 1, 0xEE, np.uint8)
+        emu.emu_cells(1, C.c_size_t(n), cells.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
+        assert (out[:n] == b).all() and out[n] == 0xEE
+        back = np.full(n + 1, 0xFFFFFFFF, np.uint32)
+        emu.emu_cells(0, C.c_size_t(n), b.ctypes.data_as(C.c_void_p), back.ctypes.data_as(C.c_void_p))
+        assert (back[:n] == b).all() and back[n] == 0xFFFFFFFF

@@ -444,3 +444,35 @@ def test_dev_calls_are_graph_capturable(pkg, torch, oracle):
     c_o, K_o = oracle.encaps(768, host(ek), m2)
     assert (host(c) == c_o).all() and (host(K) == K_o).all() and (host(K2) == K_o).all() and (host(st) == 0).all()
     e.close()
+
+
+def test_row4_converters_and_streaming_front_end(pkg, engines, torch, oracle):
+    """device cell<->byte converters and the pinned double-buffered host-resident front-end."""
+    e = engines[768]
+    g = torch.Generator(device="cuda").manual_seed(4)
+    n = 1 << 22
+    b = torch.randint(0, 256, (n + 5,), generator=g, device="cuda", dtype=torch.uint8)
+    junk = torch.randint(0, 1 << 23, (n + 5,), generator=g, device="cuda", dtype=torch.int32) << 8
+    cells = b.to(torch.int32) | junk
+    assert torch.equal(e.cells_to_bytes(cells), b)
+    assert torch.equal(e.bytes_to_cells(b), b.to(torch.int32))
+    lib = pkg.load_library()
+    n = 1000   # 4 chunks of 256 + a ragged tail, two slots
+    d, z, m = seeds("st-d", n, 1), seeds("st-z", n, 1), seeds("st-m", n, 1)
+    ek, dk = np.zeros((n, 1184), np.uint8), np.zeros((n, 2400), np.uint8)
+    assert lib.mlkem_keygen_stream(768, n, d.ctypes.data, z.ctypes.data, ek.ctypes.data, dk.ctypes.data, 256) == 0
+    c, K = np.zeros((n, 1088), np.uint8), np.zeros((n, 32), np.uint8)
+    assert lib.mlkem_encaps_stream(768, n, ek.ctypes.data, m.ctypes.data, c.ctypes.data, K.ctypes.data, 256) == 0
+    cb = c.copy()
+    cb[::97, 5] ^= 1
+    Kd, st = np.zeros((n, 32), np.uint8), np.ones(n, np.int32)
+    assert lib.mlkem_decaps_stream(768, n, dk.ctypes.data, cb.ctypes.data, Kd.ctypes.data, st.ctypes.data, 256) == 0
+    ek_o, dk_o = oracle.keygen(768, d, z)
+    c_o, K_o = oracle.encaps(768, ek_o, m)
+    Kd_o, st_o = oracle.decaps(768, dk_o, cb)
+    assert (ek == ek_o).all() and (dk == dk_o).all() and (c == c_o).all() and (K == K_o).all()
+    assert (Kd == Kd_o).all() and (st == st_o).all()
+    # single-chunk path (one slot) and empty batch
+    assert lib.mlkem_encaps_stream(768, 10, ek.ctypes.data, m.ctypes.data, c.ctypes.data, K.ctypes.data, 0) == 0
+    assert (c[:10] == c_o[:10]).all()
+    assert lib.mlkem_encaps_stream(768, 0, None, None, None, None, 0) == 0
