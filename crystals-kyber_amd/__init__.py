@@ -26,7 +26,7 @@ ERR_HASH = -5
 ABI_SYMBOLS = (
     "mlkem_sizes", "mlkem_params", "mlkem_device_count", "mlkem_strerror", "mlkem_last_hip_error",
     "mlkem_ctx_create", "mlkem_ctx_destroy", "mlkem_ctx_scratch_bytes", "mlkem_timing_begin", "mlkem_timing_end",
-    "mlkem_keygen_dev", "mlkem_encaps_dev", "mlkem_decaps_dev",
+    "mlkem_keygen_dev", "mlkem_encaps_dev", "mlkem_decaps_dev", "mlkem_encaps_status_dev", "mlkem_ctx_set_conformance",
     "mlkem_ntt_dev", "mlkem_intt_dev", "mlkem_multiply_ntts_dev", "mlkem_sample_ntt_dev", "mlkem_sample_cbd_dev",
     "mlkem_prf_dev", "mlkem_hash_dev", "mlkem_keccak_sponge_dev", "mlkem_sha3_pad_bits",
     "mlkem_keygen", "mlkem_encaps", "mlkem_decaps", "mlkem_ntt", "mlkem_intt", "mlkem_keccak_sponge",
@@ -69,6 +69,8 @@ def load_library():
     L.mlkem_keygen_dev.argtypes = [vp, i32, sz, vp, vp, vp, vp, vp]
     L.mlkem_encaps_dev.argtypes = [vp, i32, sz, vp, vp, vp, vp, vp]
     L.mlkem_decaps_dev.argtypes = [vp, i32, sz, vp, vp, vp, vp, vp]
+    L.mlkem_encaps_status_dev.argtypes = [vp, i32, sz, vp, vp, vp, vp, vp, vp]
+    L.mlkem_ctx_set_conformance.argtypes = [vp, i32]
     L.mlkem_ntt_dev.argtypes = [vp, sz, vp, vp, vp]
     L.mlkem_intt_dev.argtypes = [vp, sz, vp, vp, vp]
     L.mlkem_multiply_ntts_dev.argtypes = [vp, sz, vp, vp, vp, vp]
@@ -128,7 +130,9 @@ def sizes(param_set):
 class MLKEM:
     """One engine context = one device + its scratch HBM.  Work is enqueued on torch's current stream."""
 
-    def __init__(self, param_set=768, device=0, chunk_items=0):
+    def __init__(self, param_set=768, device=0, chunk_items=0, conformance="reference"):
+        """conformance: "reference" (default; bit-identical to ml_kem.c incl. PRF/J on SHAKE128) or "fips203"
+        (PRF/J on SHAKE256, encapsulation-key modulus check reported by `encaps(..., return_status=True)`)."""
         import torch
         self.torch = torch
         self.lib = load_library()
@@ -140,6 +144,10 @@ class MLKEM:
         h = C.c_void_p()
         self._check(self.lib.mlkem_ctx_create(C.byref(h), device, chunk_items))
         self._ctx = h
+        if conformance not in ("reference", "fips203"):
+            raise MLKEMError(-101, "conformance must be 'reference' or 'fips203'")
+        self.conformance = conformance
+        self._check(self.lib.mlkem_ctx_set_conformance(self._ctx, 1 if conformance == "fips203" else 0))
 
     def close(self):
         if getattr(self, "_ctx", None):
@@ -191,8 +199,9 @@ class MLKEM:
                                               dk.data_ptr(), self._stream()))
         return ek, dk
 
-    def encaps(self, ek, m, c=None, K=None):
-        """Encaps_internal (ml_kem.c:1093): ek [n,ek_len], m [n,32] -> c [n,c_len], K [n,32]."""
+    def encaps(self, ek, m, c=None, K=None, return_status=False):
+        """Encaps_internal (ml_kem.c:1093): ek [n,ek_len], m [n,32] -> c [n,c_len], K [n,32]
+        (+ status [n]: 0 or -4 = modulus check of KEM_Encaps / FIPS 203 7.2, when return_status)."""
         u8 = self.torch.uint8
         ek, m = self._dev(ek, u8, self.ek_len), self._dev(m, u8, 32)
         n = m.shape[0]
@@ -200,6 +209,11 @@ class MLKEM:
             raise MLKEMError(-101, "ek and m batch sizes differ")
         c = c if c is not None else self._out(n, self.c_len)
         K = K if K is not None else self._out(n, 32)
+        if return_status:
+            st = self.torch.empty(n, dtype=self.torch.int32, device=self.device)
+            self._check(self.lib.mlkem_encaps_status_dev(self._ctx, self.param_set, n, ek.data_ptr(), m.data_ptr(), c.data_ptr(),
+                                                         K.data_ptr(), st.data_ptr(), self._stream()))
+            return c, K, st
         self._check(self.lib.mlkem_encaps_dev(self._ctx, self.param_set, n, ek.data_ptr(), m.data_ptr(), c.data_ptr(),
                                               K.data_ptr(), self._stream()))
         return c, K

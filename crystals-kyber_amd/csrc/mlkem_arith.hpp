@@ -138,7 +138,9 @@ template <int K, int ETA1, int DU, int DV, bool COMPARE>
 __global__ void __launch_bounds__(WAVE * ARITH_WAVES, MLKEM_ARITH_MINWAVES)
 k_encrypt(size_t n, const uint8_t* __restrict__ ek, size_t ek_stride, const uint8_t* __restrict__ msg, const uint16_t* __restrict__ A,
           const uint8_t* __restrict__ prf, uint8_t* __restrict__ c_out, const uint8_t* __restrict__ c_in, const uint8_t* __restrict__ Kp,
-          const uint8_t* __restrict__ Kbar, uint8_t* __restrict__ Kout) {
+          const uint8_t* __restrict__ Kbar, uint8_t* __restrict__ Kout, int32_t* __restrict__ mod_status) {
+    // mod_status (optional): per-item result of the FIPS 203 encapsulation-key modulus check, 0 or -4.  The reference's
+    // own check can never fail (ml_kem.c:1273-1291, F3), so its callers pass nullptr.
     __shared__ ArithLds<K> lds_all[ARITH_WAVES];
     const int wv = (int)(threadIdx.x >> 6), l = lane_id();
     const size_t item = (size_t)blockIdx.x * ARITH_WAVES + wv;
@@ -214,11 +216,18 @@ k_encrypt(size_t n, const uint8_t* __restrict__ ek, size_t ek_stride, const uint
     // v = InverseNTT(t-hat . y-hat) + e2 + Decompress_1(m)  ->  Compress_dv, ByteEncode_dv   (ml_kem.c:867-904)
     {
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        bool over = false;
 #pragma unroll
         for (int b = 0; b < K; b++) {
             float tv[4];
             decode_regs<12, false>(L.cbuf, that[b], tv);   // raw 12-bit values (F3)
+#pragma unroll
+            for (int m = 0; m < 4; m++) over = over || (tv[m] >= F_Q);
             basemul_acc_f(acc, tv, L.vhat[b], L.vgam[b]);
+        }
+        if (mod_status) {
+            const bool bad = __ballot(over) != 0;
+            if (l == 0) mod_status[item] = bad ? -4 : 0;
         }
         wave_intt_f(acc, L.xch, tw);
         float e[4];

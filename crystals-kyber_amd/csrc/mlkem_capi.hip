@@ -219,14 +219,28 @@ int mlkem_keygen_dev(mlkem_ctx* ctx, int set, size_t n, const uint8_t* d, const 
     return MLKEM_OK;
 }
 
-int mlkem_encaps_dev(mlkem_ctx* ctx, int set, size_t n, const uint8_t* ek, const uint8_t* m, uint8_t* c, uint8_t* K, void* stream) {
+int mlkem_encaps_status_dev(mlkem_ctx* ctx, int set, size_t n, const uint8_t* ek, const uint8_t* m, uint8_t* c, uint8_t* K,
+                            int32_t* status, void* stream) {
     ParamSet p;
     if (!param_set(set, p)) return MLKEM_ERR_PARAM_SET;
     if (!ctx || (n && (!ek || !m || !c || !K))) return MLKEM_ERR_ARG;
-    if (!aligned16(ek) || !aligned16(m) || !aligned16(c) || !aligned16(K)) return MLKEM_ERR_ARG;
+    if (!aligned16(ek) || !aligned16(m) || !aligned16(c) || !aligned16(K) || (reinterpret_cast<uintptr_t>(status) & 3u)) return MLKEM_ERR_ARG;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    encaps_dispatch(st, set, n, ek, m, c, K, ctx->ws);
+    if (status && !ctx->ws.fips) {   // reference mode: the reference's modulus check can never fail (ml_kem.c:1273-1291, F3)
+        HIP_TRY(hipMemsetAsync(status, 0, n * sizeof(int32_t), st));
+        status = nullptr;
+    }
+    encaps_dispatch(st, set, n, ek, m, c, K, status, ctx->ws);
     HIP_TRY(hipGetLastError());
+    return MLKEM_OK;
+}
+int mlkem_encaps_dev(mlkem_ctx* ctx, int set, size_t n, const uint8_t* ek, const uint8_t* m, uint8_t* c, uint8_t* K, void* stream) {
+    return mlkem_encaps_status_dev(ctx, set, n, ek, m, c, K, nullptr, stream);
+}
+
+int mlkem_ctx_set_conformance(mlkem_ctx* ctx, int mode) {
+    if (!ctx || (mode != MLKEM_CONFORMANCE_REFERENCE && mode != MLKEM_CONFORMANCE_FIPS203)) return MLKEM_ERR_ARG;
+    ctx->ws.fips = mode == MLKEM_CONFORMANCE_FIPS203;
     return MLKEM_OK;
 }
 

@@ -207,9 +207,9 @@ __global__ void __launch_bounds__(WAVE) k_hash_encaps(size_t n, const uint8_t* _
 // ------------------------------------------------------------------------------------------------
 // k_hash_decaps — KEM_Decaps hash check (ml_kem.c:1336-1350) and Decaps_internal's hashing
 // (ml_kem.c:1187-1202): status = (H(dk.ek) == dk.h) ? 0 : -5 ; (K', r') = G(m' || dk.h) ; Kbar = J(dk.z || c)
-// J is SHAKE128 in the reference (F2).
+// J is SHAKE128 in the reference (F2): JRATE = 168; the FIPS 203 mode uses SHAKE256: JRATE = 136.
 // ------------------------------------------------------------------------------------------------
-template <int K, int CLEN, bool HASH_CHECK>
+template <int K, int CLEN, bool HASH_CHECK, int JRATE = 168>
 __global__ void __launch_bounds__(WAVE) k_hash_decaps(size_t n, const uint8_t* __restrict__ dk, const uint8_t* __restrict__ c,
                                                       const uint8_t* __restrict__ m_ws, uint8_t* __restrict__ Kp_ws,
                                                       uint8_t* __restrict__ r_ws, uint8_t* __restrict__ Kbar_ws,
@@ -234,7 +234,7 @@ __global__ void __launch_bounds__(WAVE) k_hash_decaps(size_t n, const uint8_t* _
     // Kbar = J(z || c)
     {
         MsgView mv{dk + 768 * K + 64, DK, 32, c, CLEN, CLEN};
-        wave_sponge_absorb<168, 0x1F>(s, stage, mv, item0, n);
+        wave_sponge_absorb<JRATE, 0x1F>(s, stage, mv, item0, n);
         if (item < n) {
             MLKEM_STATE_WORDS8(s, 0, w)
             store32(Kbar_ws, 32, item, w);
@@ -405,7 +405,27 @@ struct SampleArgs {
     // leftover[0] = count, leftover[1..] = sponge indices that need more than three squeeze blocks
     uint32_t* leftover;
     int list_mode;            // k_sample only: take the sponge indices from `leftover` (grid-stride)
+    int prf_rate;             // 0 / 168: PRF on SHAKE128 like the reference (F2) ; 136: SHAKE256 (FIPS 203 mode)
 };
+
+// PRF with eta = 3 squeezes 192 bytes: dwords 32 .. RATE/4-1 of the first block are still unwritten, then one more
+// permutation supplies dwords RATE/4 .. 47.
+template <int RATE>
+__device__ __forceinline__ void prf_eta3_tail(KeccakState& s, uint32_t* out, bool mine) {
+    constexpr int NW = RATE / 4;
+    if (mine) {
+#define MLKEM_PT(W) if constexpr (W < NW) out[W] = keccak_word<W>(s);
+        MLKEM_PT(32) MLKEM_PT(33) MLKEM_PT(34) MLKEM_PT(35) MLKEM_PT(36) MLKEM_PT(37) MLKEM_PT(38) MLKEM_PT(39) MLKEM_PT(40) MLKEM_PT(41)
+#undef MLKEM_PT
+    }
+    keccak_f1600(s);
+    if (mine) {
+#define MLKEM_PT(W) if constexpr (NW + W < 48) out[NW + W] = keccak_word<W>(s);
+        MLKEM_PT(0) MLKEM_PT(1) MLKEM_PT(2) MLKEM_PT(3) MLKEM_PT(4) MLKEM_PT(5) MLKEM_PT(6) MLKEM_PT(7)
+        MLKEM_PT(8) MLKEM_PT(9) MLKEM_PT(10) MLKEM_PT(11) MLKEM_PT(12) MLKEM_PT(13)
+#undef MLKEM_PT
+    }
+}
 
 // flush every lane-ring chunk that has become complete; ring rows live in `ring` (this wave's slice).
 // `g` is this lane's sponge index (lanes need not hold consecutive sponges), `valid` = lane owns a real sponge.
@@ -544,7 +564,8 @@ __global__ void __launch_bounds__(WAVE) k_sample(SampleArgs a) {
         MLKEM_SET_WORDS8(s, 0, seed)
         keccak_xor_byte<32>(s, ctr & 0xFFu);
         keccak_xor_byte<33>(s, 0x1F);
-        keccak_xor_byte<167>(s, 0x80);
+        if (a.prf_rate == 136) keccak_xor_byte<135>(s, 0x80);   // SHAKE256 (FIPS 203 mode)
+        else keccak_xor_byte<167>(s, 0x80);                     // SHAKE128 (the reference: ml_kem.c:508)
         keccak_f1600(s);
         uint32_t* out = reinterpret_cast<uint32_t*>(a.prf + gc * a.prf_stride);
         if (g < a.n_prf) {
@@ -554,17 +575,11 @@ __global__ void __launch_bounds__(WAVE) k_sample(SampleArgs a) {
             MLKEM_OW(16) MLKEM_OW(17) MLKEM_OW(18) MLKEM_OW(19) MLKEM_OW(20) MLKEM_OW(21) MLKEM_OW(22) MLKEM_OW(23)
             MLKEM_OW(24) MLKEM_OW(25) MLKEM_OW(26) MLKEM_OW(27) MLKEM_OW(28) MLKEM_OW(29) MLKEM_OW(30) MLKEM_OW(31)
         }
-        if (__ballot(eta == 3) != 0) {   // eta = 3 needs 192 bytes: 168 from this block + 24 from the next
-            if (g < a.n_prf && eta == 3) {
-                MLKEM_OW(32) MLKEM_OW(33) MLKEM_OW(34) MLKEM_OW(35) MLKEM_OW(36) MLKEM_OW(37) MLKEM_OW(38) MLKEM_OW(39)
-                MLKEM_OW(40) MLKEM_OW(41)
-            }
-            keccak_f1600(s);
-            if (g < a.n_prf && eta == 3) {
-                out[42] = keccak_word<0>(s); out[43] = keccak_word<1>(s); out[44] = keccak_word<2>(s);
-                out[45] = keccak_word<3>(s); out[46] = keccak_word<4>(s); out[47] = keccak_word<5>(s);
-            }
 #undef MLKEM_OW
+        if (__ballot(eta == 3) != 0) {   // eta = 3 needs 192 bytes: the rest of this block + the head of the next
+            const bool mine = g < a.n_prf && eta == 3;
+            if (a.prf_rate == 136) prf_eta3_tail<136>(s, out, mine);
+            else prf_eta3_tail<168>(s, out, mine);
         }
     }
 }

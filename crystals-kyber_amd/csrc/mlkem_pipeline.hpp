@@ -117,6 +117,8 @@ struct Workspace {
     size_t cap = 0;    // chunk capacity (items) of A / prf / leftover
     size_t hcap = 0;   // h-chunk capacity (items) of the 32-byte arrays
     int ring = 64;     // sampler LDS ring size (64 or 128 coefficients per lane)
+    int fips = 0;      // 0: bit-identical to the reference (PRF, J on SHAKE128; no-op modulus check)
+                       // 1: FIPS 203 conformant (PRF, J on SHAKE256; encaps reports status -4 for t-hat coefficients >= q)
     Workspace view(int b) const {
         Workspace w = *this;
         w.A = A2[b]; w.prf = prf2[b]; w.leftover = leftover2[b];
@@ -170,6 +172,7 @@ inline void launch_sample(stream_t st, const ParamSet& p, size_t n, const uint8_
     a.prf_stride = p.eta1 == 3 ? 192 : 128;
     a.leftover = ws.leftover;
     a.list_mode = 0;
+    a.prf_rate = ws.fips ? 136 : 168;
     zero_u32(st, ws.leftover);
     const size_t grid = a.xof_blocks + ceil_div(a.n_prf, WAVE);
     if (ws.ring == 128) launch("k_sample_main", k_sample_main<128>, grid, WAVE, st, a);
@@ -209,7 +212,7 @@ inline void keygen_run(stream_t st, const ParamSet& p, size_t n, const uint8_t* 
 // ---- ML-KEM.Encaps_internal (ml_kem.c:1093-1130) -------------------------------------------------
 template <int K, int ETA1, int DU, int DV>
 inline void encaps_run(stream_t st, const ParamSet& p, size_t n, const uint8_t* ek, const uint8_t* m, uint8_t* c, uint8_t* Kout,
-                       const Workspace& ws) {
+                       int32_t* mod_status, const Workspace& ws) {
     for (size_t h0 = 0; h0 < n; h0 += ws.hcap) {
         const size_t hn = min_sz(ws.hcap, n - h0);
         launch("k_hash_encaps", k_hash_encaps<K>, ceil_div(hn, WAVE), WAVE, st, hn, ek + h0 * p.ek_len, m + h0 * 32, Kout + h0 * 32, ws.r);
@@ -222,7 +225,8 @@ inline void encaps_run(stream_t st, const ParamSet& p, size_t n, const uint8_t* 
             launch_sample(st, p, cn, eki + 384 * K, p.ek_len, /*transpose=*/1, ws.r + c0 * 32, 2 * K + 1, K, w);
             launch("k_encrypt", k_encrypt<K, ETA1, DU, DV, false>, ceil_div(cn, ARITH_WAVES), WAVE * ARITH_WAVES,
                    pipe.arith_stream(buf), cn, eki, (size_t)p.ek_len, m + i0 * 32, (const uint16_t*)w.A, (const uint8_t*)w.prf,
-                   c + i0 * p.c_len, (const uint8_t*)nullptr, (const uint8_t*)nullptr, (const uint8_t*)nullptr, (uint8_t*)nullptr);
+                   c + i0 * p.c_len, (const uint8_t*)nullptr, (const uint8_t*)nullptr, (const uint8_t*)nullptr, (uint8_t*)nullptr,
+                   mod_status ? mod_status + i0 : (int32_t*)nullptr);
             pipe.end_chunk(buf);
         }
         pipe.join();
@@ -241,12 +245,16 @@ inline void decaps_run(stream_t st, const ParamSet& p, size_t n, const uint8_t* 
         const uint8_t* dkh = dk + h0 * p.dk_len;
         const uint8_t* ch = c + h0 * p.c_len;
         launch("k_decrypt", k_decrypt<K, DU, DV>, ceil_div(hn, ARITH_WAVES), WAVE * ARITH_WAVES, st, hn, dkh, (size_t)p.dk_len, ch, ws.m);
-        if (hash_check)
-            launch("k_hash_decaps", k_hash_decaps<K, CLEN, true>, ceil_div(hn, WAVE), WAVE, st, hn, dkh, ch, (const uint8_t*)ws.m, ws.Kp,
-                   ws.r, ws.Kbar, status ? status + h0 : nullptr);
+        int32_t* sth = (hash_check && status) ? status + h0 : (int32_t*)nullptr;
+        const size_t hgrid = ceil_div(hn, WAVE);
+        if (hash_check && !ws.fips)
+            launch("k_hash_decaps", k_hash_decaps<K, CLEN, true, 168>, hgrid, WAVE, st, hn, dkh, ch, (const uint8_t*)ws.m, ws.Kp, ws.r, ws.Kbar, sth);
+        else if (!ws.fips)
+            launch("k_hash_decaps", k_hash_decaps<K, CLEN, false, 168>, hgrid, WAVE, st, hn, dkh, ch, (const uint8_t*)ws.m, ws.Kp, ws.r, ws.Kbar, sth);
+        else if (hash_check)
+            launch("k_hash_decaps", k_hash_decaps<K, CLEN, true, 136>, hgrid, WAVE, st, hn, dkh, ch, (const uint8_t*)ws.m, ws.Kp, ws.r, ws.Kbar, sth);
         else
-            launch("k_hash_decaps", k_hash_decaps<K, CLEN, false>, ceil_div(hn, WAVE), WAVE, st, hn, dkh, ch, (const uint8_t*)ws.m, ws.Kp,
-                   ws.r, ws.Kbar, (int32_t*)nullptr);
+            launch("k_hash_decaps", k_hash_decaps<K, CLEN, false, 136>, hgrid, WAVE, st, hn, dkh, ch, (const uint8_t*)ws.m, ws.Kp, ws.r, ws.Kbar, sth);
         ChunkPipe pipe(ws, st, ceil_div(hn, ws.cap));
         for (size_t c0 = 0; c0 < hn; c0 += ws.cap) {
             const size_t cn = min_sz(ws.cap, hn - c0), i0 = h0 + c0;
@@ -257,7 +265,7 @@ inline void decaps_run(stream_t st, const ParamSet& p, size_t n, const uint8_t* 
             launch("k_encrypt_cmp", k_encrypt<K, ETA1, DU, DV, true>, ceil_div(cn, ARITH_WAVES), WAVE * ARITH_WAVES,
                    pipe.arith_stream(buf), cn, dki + 384 * K, (size_t)p.dk_len, (const uint8_t*)(ws.m + c0 * 32), (const uint16_t*)w.A,
                    (const uint8_t*)w.prf, (uint8_t*)nullptr, c + i0 * p.c_len, (const uint8_t*)(ws.Kp + c0 * 32),
-                   (const uint8_t*)(ws.Kbar + c0 * 32), Kout + i0 * 32);
+                   (const uint8_t*)(ws.Kbar + c0 * 32), Kout + i0 * 32, (int32_t*)nullptr);
             pipe.end_chunk(buf);
         }
         pipe.join();
@@ -276,13 +284,13 @@ inline int keygen_dispatch(stream_t st, int set, size_t n, const uint8_t* d, con
     return 0;
 }
 inline int encaps_dispatch(stream_t st, int set, size_t n, const uint8_t* ek, const uint8_t* m, uint8_t* c, uint8_t* K,
-                           const Workspace& ws) {
+                           int32_t* mod_status, const Workspace& ws) {
     ParamSet p;
     if (!param_set(set, p)) return -1;
     switch (set) {
-    case 512: encaps_run<2, 3, 10, 4>(st, p, n, ek, m, c, K, ws); break;
-    case 768: encaps_run<3, 2, 10, 4>(st, p, n, ek, m, c, K, ws); break;
-    default: encaps_run<4, 2, 11, 5>(st, p, n, ek, m, c, K, ws); break;
+    case 512: encaps_run<2, 3, 10, 4>(st, p, n, ek, m, c, K, mod_status, ws); break;
+    case 768: encaps_run<3, 2, 10, 4>(st, p, n, ek, m, c, K, mod_status, ws); break;
+    default: encaps_run<4, 2, 11, 5>(st, p, n, ek, m, c, K, mod_status, ws); break;
     }
     return 0;
 }

@@ -152,7 +152,8 @@ __global__ void __launch_bounds__(WAVE) k_sample_main(SampleArgs a) {
         MLKEM_SET_WORDS8(s, 0, seed)
         keccak_xor_byte<32>(s, ctr);
         keccak_xor_byte<33>(s, 0x1F);
-        keccak_xor_byte<167>(s, 0x80);
+        if (a.prf_rate == 136) keccak_xor_byte<135>(s, 0x80);   // SHAKE256 (FIPS 203 mode)
+        else keccak_xor_byte<167>(s, 0x80);                     // SHAKE128 (the reference: ml_kem.c:508)
         keccak_f1600(s);
         // stage the 128 (or 168) bytes of every lane in LDS and write them out as 16 B per lane, 8 lanes per row
         uint32_t* st32 = reinterpret_cast<uint32_t*>(ring);   // 64 rows x 33 dwords (odd stride: conflict-free)
@@ -174,20 +175,11 @@ __global__ void __launch_bounds__(WAVE) k_sample_main(SampleArgs a) {
                 *reinterpret_cast<uint4*>(a.prf + (g0 + row) * a.prf_stride + 16 * q) = v;
             }
         }
-        if (__ballot(eta == 3) != 0) {   // eta = 3: bytes 128..167 of this block + 24 bytes of the next
+        if (__ballot(eta == 3) != 0) {   // eta = 3: the rest of this block + the head of the next (192 bytes in all)
             uint32_t* out = reinterpret_cast<uint32_t*>(a.prf + gc * a.prf_stride);
             const bool mine = g < a.n_prf && eta == 3;
-            if (mine) {
-                out[32] = keccak_word<32>(s); out[33] = keccak_word<33>(s); out[34] = keccak_word<34>(s);
-                out[35] = keccak_word<35>(s); out[36] = keccak_word<36>(s); out[37] = keccak_word<37>(s);
-                out[38] = keccak_word<38>(s); out[39] = keccak_word<39>(s); out[40] = keccak_word<40>(s);
-                out[41] = keccak_word<41>(s);
-            }
-            keccak_f1600(s);
-            if (mine) {
-                out[42] = keccak_word<0>(s); out[43] = keccak_word<1>(s); out[44] = keccak_word<2>(s);
-                out[45] = keccak_word<3>(s); out[46] = keccak_word<4>(s); out[47] = keccak_word<5>(s);
-            }
+            if (a.prf_rate == 136) prf_eta3_tail<136>(s, out, mine);
+            else prf_eta3_tail<168>(s, out, mine);
         }
     }
 }

@@ -61,6 +61,14 @@ int mlkem_ctx_create(mlkem_ctx** out, int device, size_t chunk_items);
 void mlkem_ctx_destroy(mlkem_ctx* ctx);
 size_t mlkem_ctx_scratch_bytes(const mlkem_ctx* ctx);
 
+/* Conformance of a context.  REFERENCE (default): bit-identical to ml_kem.c including its deviations
+ * from FIPS 203 (PRF and J on SHAKE128: ml_kem.c:508, :546; modulus check that never fires: :1273-1291).
+ * FIPS203: PRF = SHAKE256(s || b), J = SHAKE256(z || c) (FIPS 203 section 4.1) and mlkem_encaps_status_dev reports
+ * MLKEM_ERR_MODULUS per item when ByteEncode_12(ByteDecode_12(ek)) != ek (FIPS 203 section 7.2). */
+#define MLKEM_CONFORMANCE_REFERENCE 0
+#define MLKEM_CONFORMANCE_FIPS203 1
+int mlkem_ctx_set_conformance(mlkem_ctx* ctx, int mode);
+
 /* ---- per-kernel timing (measurement aid used by bench.py) ---------------------------------------------
  * Between begin and end, every kernel launched by this thread is bracketed by HIP events on its launch
  * stream.  mlkem_timing_end synchronises and returns per-kernel-label rows: labels[32*i..] (NUL-terminated),
@@ -75,6 +83,11 @@ int mlkem_keygen_dev(mlkem_ctx* ctx, int param_set, size_t n, const uint8_t* d, 
 /* replaces Encaps_internal(params, ek, m)         ml_kem.c:1093-1130   (m : n x 32 ; c : n x c_len ; K : n x 32) */
 int mlkem_encaps_dev(mlkem_ctx* ctx, int param_set, size_t n, const uint8_t* ek, const uint8_t* m, uint8_t* c, uint8_t* K,
                      void* stream);
+/* mlkem_encaps_dev + the encapsulation-key modulus check of KEM_Encaps (ml_kem.c:1273-1291).  REFERENCE conformance:
+ * status[i] = 0 always, because the reference's check cannot fail (F3).  FIPS203 conformance: status[i] = 0, or
+ * MLKEM_ERR_MODULUS when a 12-bit coefficient of ek_i is >= q (c_i / K_i are then still written but must be discarded). */
+int mlkem_encaps_status_dev(mlkem_ctx* ctx, int param_set, size_t n, const uint8_t* ek, const uint8_t* m, uint8_t* c, uint8_t* K,
+                            int32_t* status, void* stream);
 /* replaces KEM_Decaps(params, dk, dk_len, c, c_len) ml_kem.c:1310-1359 incl. the dk hash check:
  *   status[i] = 0, or MLKEM_ERR_HASH when H(dk[384k : 768k+32]) != dk[768k+32 : 768k+64]
  *   K[i]      = Decaps_internal(dk_i, c_i) (ml_kem.c:1136-1225) — for status -5 the reference returns NULL;

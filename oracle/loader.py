@@ -74,6 +74,10 @@ class Oracle:
         L.orc_bitrev7.restype = C.c_uint
         L.orc_sample_ntt.restype = C.c_int
 
+    def set_conformance(self, fips203):
+        """0 = reference-compatible (default), 1 = FIPS 203 (PRF/J on SHAKE256, real modulus check)."""
+        self.lib.orc_set_conformance(int(bool(fips203)))
+
     # -- batch KEM ---------------------------------------------------------------------
     def keygen(self, pset, d, z):
         ekl, dkl, _ = SIZES[pset]

@@ -147,17 +147,24 @@ void orc_sha3_512(const uint8_t *in, size_t n, uint8_t out[64]) { orc_sponge(72,
 void orc_shake128(const uint8_t *in, size_t n, uint8_t *out, size_t outlen) { orc_sponge(168, 0x1F, in, n, out, outlen); }
 void orc_shake256(const uint8_t *in, size_t n, uint8_t *out, size_t outlen) { orc_sponge(136, 0x1F, in, n, out, outlen); }
 
-/* ml_kem.c:496-515 — PRF_eta(s, b): the reference passes c = N = 256 => SHAKE128 (F2). */
+static int g_fips203 = 0;
+void orc_set_conformance(int fips203) { g_fips203 = fips203 != 0; }
+
+/* ml_kem.c:496-515 — PRF_eta(s, b): the reference passes c = N = 256 => SHAKE128 (F2); FIPS 203 4.1: SHAKE256. */
 void orc_prf(const uint8_t s[32], uint8_t b, unsigned eta, uint8_t *out) {
     uint8_t in[33];
     memcpy(in, s, 32);
     in[32] = b;
-    orc_shake128(in, 33, out, 64 * eta);
+    if (g_fips203) orc_shake256(in, 33, out, 64 * eta);
+    else orc_shake128(in, 33, out, 64 * eta);
 }
 /* ml_kem.c:521-534 — H = SHA3-256 */
 void orc_H(const uint8_t *in, size_t n, uint8_t out[32]) { orc_sha3_256(in, n, out); }
 /* ml_kem.c:540-553 — J: capacity 256 => SHAKE128 (F2), 32 bytes out */
-void orc_J(const uint8_t *in, size_t n, uint8_t out[32]) { orc_shake128(in, n, out, 32); }
+void orc_J(const uint8_t *in, size_t n, uint8_t out[32]) {
+    if (g_fips203) orc_shake256(in, n, out, 32);
+    else orc_shake128(in, n, out, 32);
+}
 /* ml_kem.c:559-572 — G = SHA3-512 */
 void orc_G(const uint8_t *in, size_t n, uint8_t out[64]) { orc_sha3_512(in, n, out); }
 
@@ -498,6 +505,8 @@ int orc_kem_encaps_check(int set, const uint8_t *ek, unsigned ek_len) {
         uint16_t t[256];
         uint8_t back[384];
         orc_byte_decode(ek + 384 * i, 12, t);
+        if (g_fips203)   /* FIPS 203 ByteDecode_12 reduces mod q, so a coefficient >= q changes the re-encoding */
+            for (unsigned j = 0; j < 256; j++) t[j] = (uint16_t)(t[j] % ORC_Q);
         orc_byte_encode(t, 12, back);
         if (memcmp(back, ek + 384 * i, 384) != 0) return -4;
     }

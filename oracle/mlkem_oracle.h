@@ -30,6 +30,12 @@ typedef struct {
     unsigned ek_len, dk_len, c_len;
 } orc_params;
 
+/* Conformance switch of the CHECKER (process-global; tests are single-threaded): 0 = reference-compatible (default:
+ * PRF and J on SHAKE128 like ml_kem.c:508, :546), 1 = FIPS 203 (PRF and J on SHAKE256, real modulus check).  The FIPS
+ * mode has no vectors in the reference; it is pinned by hashlib (SHAKE256) and an independent pure-Python restatement
+ * of FIPS 203 in tests/test_fips203_mode.py. */
+void orc_set_conformance(int fips203);
+
 /* ml_kem.c:1363-1395 (init).  Returns 0, or -1 for an unknown parameter set. */
 int orc_params_init(int set, orc_params *p);
 

@@ -10,7 +10,7 @@
 using namespace mlkem;
 
 static size_t g_cap = 0, g_hcap = 0;
-static int g_ring = 64;
+static int g_ring = 64, g_fips = 0;
 
 static void* xalloc(size_t bytes) { return aligned_alloc(64, (bytes + 127) / 64 * 64); }
 
@@ -20,6 +20,7 @@ static Workspace make_ws(size_t n) {
     ws.hcap = g_hcap ? g_hcap : (n ? n : 1);
     if (ws.hcap < ws.cap) ws.hcap = ws.cap;
     ws.ring = g_ring;
+    ws.fips = g_fips;
     for (int b = 0; b < 2; b++) {
         ws.A2[b] = (uint16_t*)xalloc(ws.cap * 16 * 512);
         ws.prf2[b] = (uint8_t*)xalloc(ws.cap * 9 * 192);
@@ -40,15 +41,16 @@ static void free_ws(Workspace& ws) {
 
 extern "C" {
 void emu_config(size_t cap, size_t hcap, int ring) { g_cap = cap; g_hcap = hcap; g_ring = ring == 128 ? 128 : 64; }
+void emu_conformance(int fips) { g_fips = fips != 0; }
 int emu_keygen(int set, size_t n, const uint8_t* d, const uint8_t* z, uint8_t* ek, uint8_t* dk) {
     Workspace ws = make_ws(n);
     int rc = keygen_dispatch(nullptr, set, n, d, z, ek, dk, ws);
     free_ws(ws);
     return rc;
 }
-int emu_encaps(int set, size_t n, const uint8_t* ek, const uint8_t* m, uint8_t* c, uint8_t* K) {
+int emu_encaps(int set, size_t n, const uint8_t* ek, const uint8_t* m, uint8_t* c, uint8_t* K, int32_t* status) {
     Workspace ws = make_ws(n);
-    int rc = encaps_dispatch(nullptr, set, n, ek, m, c, K, ws);
+    int rc = encaps_dispatch(nullptr, set, n, ek, m, c, K, status, ws);
     free_ws(ws);
     return rc;
 }

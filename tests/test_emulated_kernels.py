@@ -85,7 +85,7 @@ def test_emu_kem_matches_oracle_and_golden(emu, oracle, golden, pset):
     assert (ek == ek_o).all() and (dk == dk_o).all()
     assert bytes(ek[0]).hex() == g["ek"] and bytes(dk[0]).hex() == g["dk"]
     c, K = np.zeros((n, cl), np.uint8), np.zeros((n, 32), np.uint8)
-    assert emu.emu_encaps(pset, C.c_size_t(n), p8(ek), p8(m), p8(c), p8(K)) == 0
+    assert emu.emu_encaps(pset, C.c_size_t(n), p8(ek), p8(m), p8(c), p8(K), None) == 0
     c_o, K_o = oracle.encaps(pset, ek, m)
     assert (c == c_o).all() and (K == K_o).all()
     assert bytes(c[0]).hex() == g["c"] and bytes(K[0]).hex() == g["K"]
@@ -134,7 +134,7 @@ def test_emu_chunk_and_hchunk_loops(emu, oracle):
         ek_o, dk_o = oracle.keygen(pset, d, z)
         assert (ek == ek_o).all() and (dk == dk_o).all()
         c, K = np.zeros((n, cl), np.uint8), np.zeros((n, 32), np.uint8)
-        assert emu.emu_encaps(pset, C.c_size_t(n), p8(ek), p8(m), p8(c), p8(K)) == 0
+        assert emu.emu_encaps(pset, C.c_size_t(n), p8(ek), p8(m), p8(c), p8(K), None) == 0
         c_o, K_o = oracle.encaps(pset, ek, m)
         assert (c == c_o).all() and (K == K_o).all()
         cb = c.copy()
