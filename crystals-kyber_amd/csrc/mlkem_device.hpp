@@ -89,12 +89,29 @@ __device__ __forceinline__ void rotl64(uint32_t lo, uint32_t hi, uint32_t& olo, 
     }
 }
 
+// theta is applied in one of two forms (same result):
+//   MLKEM_KECCAK_DFORM 0 : A ^ C[x-1] ^ rotl(C[x+1], 1) as one v_bitop3 per half-lane; C and rotl(C) (20 registers) stay
+//                          live through rho/pi  -> 180 VALU per round, 78 VGPRs for the bare permutation
+//   MLKEM_KECCAK_DFORM 1 : D[x] = C[x-1] ^ rotl(C[x+1], 1) materialised first (10 registers live), then A ^ D
+//                          -> 190 VALU per round but a smaller live set
+#ifndef MLKEM_KECCAK_DFORM
+#define MLKEM_KECCAK_DFORM 0
+#endif
+#if MLKEM_KECCAK_DFORM
+#define MLKEM_RHOPI(dst, src, rot, dx)                                                       \
+    {                                                                                        \
+        uint32_t tl = s.lo[src] ^ dl[dx];                                                    \
+        uint32_t th = s.hi[src] ^ dh[dx];                                                    \
+        rotl64<rot>(tl, th, bl[dst], bh[dst]);                                               \
+    }
+#else
 #define MLKEM_RHOPI(dst, src, rot, dx)                                                       \
     {                                                                                        \
         uint32_t tl = MLKEM_XOR3(s.lo[src], cl[(dx + 4) % 5], rl[(dx + 1) % 5]);             \
         uint32_t th = MLKEM_XOR3(s.hi[src], ch[(dx + 4) % 5], rh[(dx + 1) % 5]);             \
         rotl64<rot>(tl, th, bl[dst], bh[dst]);                                               \
     }
+#endif
 
 __device__ __forceinline__ void keccak_f1600(KeccakState& s) {
 #pragma unroll 1
@@ -108,6 +125,14 @@ __device__ __forceinline__ void keccak_f1600(KeccakState& s) {
         }
 #pragma unroll
         for (int x = 0; x < 5; x++) rotl64<1>(cl[x], ch[x], rl[x], rh[x]);
+#if MLKEM_KECCAK_DFORM
+        uint32_t dl[5], dh[5];
+#pragma unroll
+        for (int x = 0; x < 5; x++) {
+            dl[x] = cl[(x + 4) % 5] ^ rl[(x + 1) % 5];
+            dh[x] = ch[(x + 4) % 5] ^ rh[(x + 1) % 5];
+        }
+#endif
         // theta-apply + rho (sha3.c:53-84) + pi (sha3.c:88-112): B[y, 2x+3y] = rotl(A[x, y] ^ D[x], r[x, y])
         MLKEM_RHOPI(0, 0, 0, 0)   MLKEM_RHOPI(10, 1, 1, 1)  MLKEM_RHOPI(20, 2, 62, 2) MLKEM_RHOPI(5, 3, 28, 3)  MLKEM_RHOPI(15, 4, 27, 4)
         MLKEM_RHOPI(16, 5, 36, 0) MLKEM_RHOPI(1, 6, 44, 1)  MLKEM_RHOPI(11, 7, 6, 2)  MLKEM_RHOPI(21, 8, 55, 3) MLKEM_RHOPI(6, 9, 20, 4)
@@ -152,9 +177,54 @@ __device__ __forceinline__ uint32_t& keccak_word(KeccakState& s) {
 // wave-level helpers
 // ----------------------------------------------------------------------------------------------
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+// lane id the compiler cannot merge with an earlier lane_id(): values derived from it are recomputed where they are
+// used instead of being kept in registers across a permutation
+__device__ __forceinline__ int lane_id_fresh() {
+    int l = lane_id();
+#ifndef MLKEM_EMU
+    asm volatile("" : "+v"(l));
+#endif
+    return l;
+}
 // Order wave-private LDS traffic between lanes of ONE wave (DS ops of a wave execute in issue order;
 // this only stops the compiler from moving them).
 __device__ __forceinline__ void wave_lds_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); }
+
+// stop the instruction scheduler from moving anything across this point (no code is emitted): used to bound how many
+// LDS reads are in flight, i.e. how many VGPRs a staging step may hold next to the 50-register Keccak state
+__device__ __forceinline__ void sched_fence() {
+#ifndef MLKEM_EMU
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+}
+
+// LDS-DMA (global_load_lds_dword): every enabled lane fetches the 4 bytes at uniform_base + its lane_offset and the
+// memory pipe writes them to dword `lane` of the 256-byte LDS chunk `lds_chunk` (wave-uniform) without passing
+// through VGPRs; completion is tracked by vmcnt.  lds_dma_begin() orders the issue after the wave's earlier LDS
+// reads of the same buffer; lds_dma_wait() must precede the first LDS read of the fetched data.
+__device__ __forceinline__ void lds_dma_dword(const uint8_t* uniform_base, unsigned lane_offset, uint32_t* lds_chunk) {
+#ifdef MLKEM_EMU
+    lds_chunk[lane_id()] = *reinterpret_cast<const uint32_t*>(uniform_base + lane_offset);
+#else
+    // wave-uniform 64-bit base + zero-extended 32-bit per-lane offset: selects the SGPR-base + VGPR-offset addressing
+    // form, so a DMA instruction needs one VGPR instead of a 64-bit per-lane address
+    typedef const __attribute__((address_space(1))) uint8_t* gptr_t;
+    gptr_t g = (gptr_t)uniform_base;
+    __builtin_amdgcn_global_load_lds(
+        reinterpret_cast<const __attribute__((address_space(1))) uint32_t*>(g + lane_offset),
+        reinterpret_cast<__attribute__((address_space(3))) uint32_t*>(reinterpret_cast<uintptr_t>(lds_chunk)), 4, 0, 0);
+#endif
+}
+__device__ __forceinline__ void lds_dma_begin() {
+#ifndef MLKEM_EMU
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+}
+__device__ __forceinline__ void lds_dma_wait() {
+#ifndef MLKEM_EMU
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+}
 
 // ----------------------------------------------------------------------------------------------
 // Coefficient layouts of the one-polynomial-per-wave NTT (mlkem_fntt.hpp).  Lane l holds 4 coefficients x[0..3]:

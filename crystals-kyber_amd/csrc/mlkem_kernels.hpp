@@ -17,6 +17,14 @@ namespace mlkem {
 
 constexpr int WAVE = 64;
 
+// Resident waves per SIMD the Keccak kernels are compiled for (second __launch_bounds__ argument = register budget
+// 512 / N per lane).  The lane-sliced permutation is a long dependent VALU stream: measured with tools/keccak_ubench.hip
+// it costs 357 / 313 / 288 / 270 ns per round per wave at 3 / 4 / 5 / 6 resident waves, so occupancy is worth more than
+// anything the compiler buys with extra registers.
+#ifndef MLKEM_KECCAK_MINWAVES
+#define MLKEM_KECCAK_MINWAVES 6
+#endif
+
 // ================================================================================================
 // LDS-staged absorption: 64 lanes each own one sponge.  For every rate block the wave reads the 64 rows
 // (one per item) x RATE bytes of a virtual message made of two segments (seg0 then seg1, each with its own
@@ -49,7 +57,11 @@ __device__ __forceinline__ uint2 load_qword_tail(const uint8_t* p, unsigned avai
 #ifndef MLKEM_STAGE_ROWS
 #define MLKEM_STAGE_ROWS 32
 #endif
+#ifndef MLKEM_STAGE_DMA
+#define MLKEM_STAGE_DMA 1
+#endif
 constexpr int STAGE_ROWS = MLKEM_STAGE_ROWS;
+constexpr int STAGE_GROUP = MLKEM_STAGE_DMA ? 2 : 7;
 constexpr int STAGE_PARTS = WAVE / STAGE_ROWS;
 
 template <int RATE>
@@ -57,12 +69,13 @@ __device__ __forceinline__ void wave_stage_block(uint2* stage, const MsgView& mv
                                                  int part) {
     constexpr int NQ = RATE / 8, TOT = STAGE_ROWS * NQ, ITERS = (TOT + WAVE - 1) / WAVE;
     const unsigned l = (unsigned)lane_id(), total = mv.len0 + mv.len1;
-    // loads are issued in groups of 7 (7 x 8 B per lane in flight): enough memory-level parallelism without
-    // pushing the kernel past 128 VGPRs next to the 50-register Keccak state
+    // loads are issued in groups of STAGE_GROUP (x 8 B per lane in flight).  With the LDS-DMA path compiled in, this
+    // synchronous path only serves ragged last waves and odd message shapes, so it is kept register-lean (groups of 2);
+    // without it, groups of 7 give enough memory-level parallelism next to the 50-register Keccak state.
 #pragma unroll 1
-    for (int it0 = 0; it0 < ITERS; it0 += 7)
+    for (int it0 = 0; it0 < ITERS; it0 += STAGE_GROUP)
 #pragma unroll
-    for (int it = it0; it < it0 + 7; it++) {
+    for (int it = it0; it < it0 + STAGE_GROUP; it++) {
         if (it >= ITERS) break;
         const unsigned f = (unsigned)it * WAVE + l;
         if (TOT % WAVE != 0 && f >= (unsigned)TOT) break;
@@ -108,12 +121,114 @@ __device__ __forceinline__ void wave_absorb_block(KeccakState& s, uint2* stage, 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Asynchronous variant of the staging above (MLKEM_STAGE_DMA, default on): the rate block is fetched with LDS-DMA
+// loads (mlkem_device.hpp: lds_dma_dword) that cost neither VGPRs nor issue slots for LDS stores.  The wave's 64 rows
+// are staged as two halves of 32 rows through ONE 32-row buffer (4.5 KB at rate 136, 5.5 KB at rate 168, so that six
+// waves per SIMD stay resident): half 0 of block b+1 is issued right after block b has been XORed into the states and
+// is in flight during the permutation of block b; half 1 follows as soon as half 0 has been consumed.
+// One DMA instruction moves 16 rows x 16 bytes (lane -> row lane/4, dword lane%4: 16-byte runs per row, one base per
+// row group); the buffer is laid out [row group g = 0..1][16-byte column j][row 0..15][4 dwords], so lane L later reads
+// its row (group (L/16)%2, row L%16) with one conflict-free ds_read_b128 per column.
+// Preconditions (checked per sponge, wave-uniform; otherwise the synchronous path above runs): a full wave of items,
+// message length % 4 == 0, len0 % 16 == 0 when there are two segments, strides < 2^27.
+// ------------------------------------------------------------------------------------------------
+#ifndef MLKEM_STAGE_DMA
+#define MLKEM_STAGE_DMA 1
+#endif
+template <int RATE>
+struct DmaStage {
+    static constexpr int NW = RATE / 4;            // dwords per row
+    static constexpr int NJ = (NW + 3) / 4;        // 16-byte columns per row
+    static constexpr int DWORDS = 2 * NJ * WAVE;   // 2 row groups x NJ chunks x 64 dwords
+};
+
+// issue the loads of rows 32*half .. 32*half+31 of the rate block at message offset voff;
+// valid = message bytes in this block (<= RATE, % 4 == 0)
+template <int RATE>
+__device__ __forceinline__ void wave_dma_half(uint32_t* stage, const MsgView& mv, size_t item0, unsigned voff, unsigned valid,
+                                              int half) {
+    using D = DmaStage<RATE>;
+    const unsigned l = (unsigned)lane_id_fresh(), rr = l >> 2, c4 = 4u * (l & 3u);
+    const unsigned off0 = rr * (unsigned)mv.stride0 + c4, off1 = rr * (unsigned)mv.stride1 + c4;
+    lds_dma_begin();
+#pragma unroll
+    for (int j = 0; j < D::NJ; j++) {
+        const unsigned pos = 16u * (unsigned)j;
+        const bool seg0 = voff + pos < mv.len0;
+        const uint8_t* base = seg0 ? mv.p0 + (voff + pos) : mv.p1 + (voff + pos - mv.len0);
+        const size_t stride = seg0 ? mv.stride0 : mv.stride1;
+        const unsigned off = seg0 ? off0 : off1;
+        if (pos + c4 < valid) {
+#pragma unroll
+            for (int g = 0; g < 2; g++)
+                lds_dma_dword(base + (item0 + (size_t)(32 * half + 16 * g)) * stride, off, stage + (g * D::NJ + j) * WAVE);
+        }
+    }
+}
+
+// XOR the first `valid` bytes of the staged row into the state of every lane of half `half`.  Branch-free across lanes:
+// every lane reads the row slot (L % 32) and folds it in with s ^= (v & m), m = all-ones in the owning half (one
+// v_bitop3 per dword) -- a lane-divergent `if` around 2 x 25 state registers makes the compiler keep two copies of the
+// state.  FULL = the whole rate block is message (no per-dword length tests).
+template <int RATE, bool FULL>
+__device__ __forceinline__ void lane_xor_dma(KeccakState& s, const uint32_t* stage, unsigned valid, int half) {
+    using D = DmaStage<RATE>;
+    const int l = lane_id_fresh();
+    const uint32_t m = (l >> 5) == half ? 0xFFFFFFFFu : 0u;
+    const uint32_t* row = stage + ((l >> 4) & 1) * (D::NJ * WAVE) + (l & 15) * 4;
+#pragma unroll
+    for (int j = 0; j < D::NJ; j++) {
+        if (FULL || 16u * (unsigned)j < valid) {   // wave-uniform
+            const uint4 v = *reinterpret_cast<const uint4*>(row + WAVE * j);
+            const uint32_t d[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int w = 4 * j + k;
+                if (w < D::NW && (FULL || 4u * (unsigned)w < valid)) {
+                    if (w & 1) s.hi[w >> 1] = __builtin_amdgcn_bitop3_b32(s.hi[w >> 1], d[k], m, 0x78);   // a ^ (b & c)
+                    else s.lo[w >> 1] = __builtin_amdgcn_bitop3_b32(s.lo[w >> 1], d[k], m, 0x78);
+                }
+            }
+        }
+    }
+}
+// Make the first NQ state lanes "opaque" at this point (no code): the XORs that produced them cannot be sunk past it.
+// Without it the compiler keeps the 34-42 staged dwords of half 0 in registers, fetches half 1, and folds both in at
+// once -- twice the staging registers next to the 50-register state.
+template <int NQ>
+__device__ __forceinline__ void pin_state(KeccakState& s) {
+#ifndef MLKEM_EMU
+#pragma unroll
+    for (int w = 0; w < NQ; w++) {
+        asm volatile("" : "+v"(s.lo[w]));
+        asm volatile("" : "+v"(s.hi[w]));
+    }
+#endif
+}
+// both halves of one rate block: half 0 is already in flight on entry
+template <int RATE, bool FULL>
+__device__ __forceinline__ void wave_absorb_dma(KeccakState& s, uint32_t* st32, const MsgView& mv, size_t item0, unsigned voff,
+                                                unsigned valid) {
+    lds_dma_wait();
+    wave_lds_fence();
+    lane_xor_dma<RATE, FULL>(s, st32, valid, 0);
+    pin_state<RATE / 8>(s);
+    wave_lds_fence();
+    wave_dma_half<RATE>(st32, mv, item0, voff, valid, 1);
+    lds_dma_wait();
+    wave_lds_fence();
+    lane_xor_dma<RATE, FULL>(s, st32, valid, 1);
+    pin_state<RATE / 8>(s);
+    wave_lds_fence();
+}
+
 // xor `byte` at runtime byte position `pos` (wave-uniform) — used for the domain/pad byte of a
 // message whose length is only known at run time
 __device__ __forceinline__ void keccak_xor_byte_rt(KeccakState& s, unsigned pos, uint32_t byte) {
     const unsigned w = pos >> 2;
     const uint32_t v = byte << (8 * (pos & 3));
-#define MLKEM_XB(W) if (w == W) keccak_word<W>(s) ^= v;
+#define MLKEM_XB(W) keccak_word<W>(s) ^= (w == W) ? v : 0u;   // select, not `if`: an if-chain is turned into a dynamic state index (scratch)
     MLKEM_XB(0) MLKEM_XB(1) MLKEM_XB(2) MLKEM_XB(3) MLKEM_XB(4) MLKEM_XB(5) MLKEM_XB(6) MLKEM_XB(7)
     MLKEM_XB(8) MLKEM_XB(9) MLKEM_XB(10) MLKEM_XB(11) MLKEM_XB(12) MLKEM_XB(13) MLKEM_XB(14) MLKEM_XB(15)
     MLKEM_XB(16) MLKEM_XB(17) MLKEM_XB(18) MLKEM_XB(19) MLKEM_XB(20) MLKEM_XB(21) MLKEM_XB(22) MLKEM_XB(23)
@@ -130,6 +245,27 @@ __device__ __forceinline__ void wave_sponge_absorb(KeccakState& s, uint2* stage,
                                                    size_t n_items) {
     const unsigned total = mv.len0 + mv.len1;
     keccak_zero(s);
+#if MLKEM_STAGE_DMA
+    if (item0 + WAVE <= n_items && total != 0 && total % 4 == 0 && (mv.len1 == 0 || mv.len0 % 16 == 0) &&
+        mv.stride0 < (1u << 27) && mv.stride1 < (1u << 27)) {
+        uint32_t* st32 = reinterpret_cast<uint32_t*>(stage);
+        const unsigned nfull = total / (unsigned)RATE, rem = total - nfull * (unsigned)RATE;
+        wave_dma_half<RATE>(st32, mv, item0, 0, nfull ? (unsigned)RATE : rem, 0);
+#pragma unroll 1
+        for (unsigned b = 0; b < nfull; b++) {
+            wave_absorb_dma<RATE, true>(s, st32, mv, item0, b * RATE, RATE);
+            // half 0 of the next block (or of the partial tail) is in flight during the permutation
+            if (b + 1 < nfull) wave_dma_half<RATE>(st32, mv, item0, (b + 1) * RATE, RATE, 0);
+            else if (rem) wave_dma_half<RATE>(st32, mv, item0, nfull * RATE, rem, 0);
+            keccak_f1600(s);
+        }
+        if (rem) wave_absorb_dma<RATE, false>(s, st32, mv, item0, nfull * RATE, rem);
+        keccak_xor_byte_rt(s, rem, SUFFIX);
+        keccak_xor_byte<RATE - 1>(s, 0x80);
+        keccak_f1600(s);
+        return;
+    }
+#endif
     unsigned voff = 0;
     while (total - voff >= (unsigned)RATE) {
         wave_absorb_block<RATE>(s, stage, mv, item0, n_items, voff);
@@ -143,7 +279,14 @@ __device__ __forceinline__ void wave_sponge_absorb(KeccakState& s, uint2* stage,
     keccak_f1600(s);
 }
 
-constexpr int STAGE_QWORDS = STAGE_ROWS * (168 / 8);   // largest rate (SHAKE128): 5376 bytes per wave at 32 rows
+// stage size per wave: the synchronous path needs STAGE_ROWS rows of the largest rate (5376 bytes at 32 rows); the DMA
+// path needs 32 rows in 16-byte columns (DmaStage).  Kernels that only hash at rate 136 use the smaller figure.
+constexpr int stage_qwords(int max_rate) {
+    const int sync_q = STAGE_ROWS * (max_rate / 8);
+    const int dma_q = MLKEM_STAGE_DMA ? 2 * ((max_rate / 4 + 3) / 4) * WAVE / 2 : 0;
+    return sync_q > dma_q ? sync_q : dma_q;
+}
+constexpr int STAGE_QWORDS = stage_qwords(168);
 
 // store / load 8 dwords (32 bytes) of per-item data: row `item` of a [n][32]-byte array
 __device__ __forceinline__ void store32(uint8_t* base, size_t stride, size_t item, const uint32_t (&w)[8]) {
@@ -183,9 +326,9 @@ __device__ __forceinline__ void lane_G64(KeccakState& s, const uint32_t (&x)[8],
 // k_hash_encaps — Encaps_internal's hashing (ml_kem.c:1108-1124): h = H(ek); (K, r) = G(m || h)
 // ------------------------------------------------------------------------------------------------
 template <int K>
-__global__ void __launch_bounds__(WAVE) k_hash_encaps(size_t n, const uint8_t* __restrict__ ek, const uint8_t* __restrict__ m,
+__global__ void __launch_bounds__(WAVE, MLKEM_KECCAK_MINWAVES) k_hash_encaps(size_t n, const uint8_t* __restrict__ ek, const uint8_t* __restrict__ m,
                                                       uint8_t* __restrict__ Kout, uint8_t* __restrict__ r_ws) {
-    __shared__ __attribute__((aligned(16))) uint2 stage[STAGE_QWORDS];
+    __shared__ __attribute__((aligned(16))) uint2 stage[stage_qwords(136)];
     constexpr unsigned EK = 384 * K + 32;
     const size_t item0 = (size_t)blockIdx.x * WAVE, item = item0 + lane_id();
     KeccakState s;
@@ -210,7 +353,7 @@ __global__ void __launch_bounds__(WAVE) k_hash_encaps(size_t n, const uint8_t* _
 // J is SHAKE128 in the reference (F2): JRATE = 168; the FIPS 203 mode uses SHAKE256: JRATE = 136.
 // ------------------------------------------------------------------------------------------------
 template <int K, int CLEN, bool HASH_CHECK, int JRATE = 168>
-__global__ void __launch_bounds__(WAVE) k_hash_decaps(size_t n, const uint8_t* __restrict__ dk, const uint8_t* __restrict__ c,
+__global__ void __launch_bounds__(WAVE, MLKEM_KECCAK_MINWAVES) k_hash_decaps(size_t n, const uint8_t* __restrict__ dk, const uint8_t* __restrict__ c,
                                                       const uint8_t* __restrict__ m_ws, uint8_t* __restrict__ Kp_ws,
                                                       uint8_t* __restrict__ r_ws, uint8_t* __restrict__ Kbar_ws,
                                                       int32_t* __restrict__ status) {
@@ -257,7 +400,7 @@ __global__ void __launch_bounds__(WAVE) k_hash_decaps(size_t n, const uint8_t* _
 // k_hash_keygen_seed — K-PKE.KeyGen's (rho, sigma) = G(d || k) (ml_kem.c:674-681)
 // ------------------------------------------------------------------------------------------------
 template <int K>
-__global__ void __launch_bounds__(WAVE) k_hash_keygen_seed(size_t n, const uint8_t* __restrict__ d, uint8_t* __restrict__ rho_ws,
+__global__ void __launch_bounds__(WAVE, MLKEM_KECCAK_MINWAVES) k_hash_keygen_seed(size_t n, const uint8_t* __restrict__ d, uint8_t* __restrict__ rho_ws,
                                                            uint8_t* __restrict__ sigma_ws) {
     const size_t item = (size_t)blockIdx.x * WAVE + lane_id();
     const size_t it = item < n ? item : n - 1;
@@ -282,9 +425,9 @@ __global__ void __launch_bounds__(WAVE) k_hash_keygen_seed(size_t n, const uint8
 // k_hash_keygen_fin — KeyGen_internal's dk tail (ml_kem.c:1065-1077): dk[768k+32 ..] = H(ek) ; dk[768k+64 ..] = z
 // ------------------------------------------------------------------------------------------------
 template <int K>
-__global__ void __launch_bounds__(WAVE) k_hash_keygen_fin(size_t n, const uint8_t* __restrict__ ek, const uint8_t* __restrict__ z,
+__global__ void __launch_bounds__(WAVE, MLKEM_KECCAK_MINWAVES) k_hash_keygen_fin(size_t n, const uint8_t* __restrict__ ek, const uint8_t* __restrict__ z,
                                                           uint8_t* __restrict__ dk) {
-    __shared__ __attribute__((aligned(16))) uint2 stage[STAGE_QWORDS];
+    __shared__ __attribute__((aligned(16))) uint2 stage[stage_qwords(136)];
     constexpr unsigned EK = 384 * K + 32, DK = 768 * K + 96;
     const size_t item0 = (size_t)blockIdx.x * WAVE, item = item0 + lane_id();
     KeccakState s;
@@ -301,22 +444,22 @@ __global__ void __launch_bounds__(WAVE) k_hash_keygen_fin(size_t n, const uint8_
 
 // ------------------------------------------------------------------------------------------------
 // k_hash_batch — stand-alone H / G / J over equal-length messages (parity tests of the staged sponge)
-//   kind 0: H = SHA3-256 (32 B out), 1: G = SHA3-512 (64 B out), 2: J = SHAKE128 (32 B out)
+//   KIND 0: H = SHA3-256 (32 B out), 1: G = SHA3-512 (64 B out), 2: J = SHAKE128 (32 B out)
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(WAVE) k_hash_batch(size_t n, int kind, const uint8_t* __restrict__ msg, unsigned len,
-                                                     size_t stride, uint8_t* __restrict__ out) {
-    __shared__ __attribute__((aligned(16))) uint2 stage[STAGE_QWORDS];
+template <int KIND>
+__global__ void __launch_bounds__(WAVE, MLKEM_KECCAK_MINWAVES) k_hash_batch(size_t n, const uint8_t* __restrict__ msg, unsigned len,
+                                                                            size_t stride, uint8_t* __restrict__ out) {
+    constexpr int RATE = KIND == 0 ? 136 : KIND == 1 ? 72 : 168;
+    __shared__ __attribute__((aligned(16))) uint2 stage[stage_qwords(RATE)];
     const size_t item0 = (size_t)blockIdx.x * WAVE, item = item0 + lane_id();
     KeccakState s;
     MsgView mv{msg, stride, len, msg, stride, 0};
     uint32_t w[8];
-    if (kind == 0) wave_sponge_absorb<136, 0x06>(s, stage, mv, item0, n);
-    else if (kind == 1) wave_sponge_absorb<72, 0x06>(s, stage, mv, item0, n);
-    else wave_sponge_absorb<168, 0x1F>(s, stage, mv, item0, n);
+    wave_sponge_absorb<RATE, KIND == 2 ? 0x1F : 0x06>(s, stage, mv, item0, n);
     if (item < n) {
         MLKEM_STATE_WORDS8(s, 0, w)
-        store32(out, kind == 1 ? 64 : 32, item, w);
-        if (kind == 1) {
+        store32(out, KIND == 1 ? 64 : 32, item, w);
+        if (KIND == 1) {
             MLKEM_STATE_WORDS8(s, 8, w)
             store32(out + 32, 64, item, w);
         }
@@ -410,17 +553,22 @@ struct SampleArgs {
 
 // PRF with eta = 3 squeezes 192 bytes: dwords 32 .. RATE/4-1 of the first block are still unwritten, then one more
 // permutation supplies dwords RATE/4 .. 47.
-template <int RATE>
-__device__ __forceinline__ void prf_eta3_tail(KeccakState& s, uint32_t* out, bool mine) {
-    constexpr int NW = RATE / 4;
+// `out_of_lane()` yields the lane's output row; it is called again after the permutation so that a caller can hand in a
+// recomputation (from lane_id_fresh() and wave-uniform values) instead of keeping a 64-bit pointer alive across it.
+// `rate` (136 or 168, wave-uniform) is a run-time value so that there is ONE permutation in the code path.
+template <class OutFn>
+__device__ __forceinline__ void prf_eta3_tail(KeccakState& s, unsigned rate, OutFn out_of_lane, bool mine) {
+    const unsigned nw = rate / 4;
     if (mine) {
-#define MLKEM_PT(W) if constexpr (W < NW) out[W] = keccak_word<W>(s);
+        uint32_t* out = out_of_lane();
+#define MLKEM_PT(W) if (W < nw) out[W] = keccak_word<W>(s);
         MLKEM_PT(32) MLKEM_PT(33) MLKEM_PT(34) MLKEM_PT(35) MLKEM_PT(36) MLKEM_PT(37) MLKEM_PT(38) MLKEM_PT(39) MLKEM_PT(40) MLKEM_PT(41)
 #undef MLKEM_PT
     }
     keccak_f1600(s);
     if (mine) {
-#define MLKEM_PT(W) if constexpr (NW + W < 48) out[NW + W] = keccak_word<W>(s);
+        uint32_t* out = out_of_lane() + nw;
+#define MLKEM_PT(W) if (nw + W < 48u) out[W] = keccak_word<W>(s);
         MLKEM_PT(0) MLKEM_PT(1) MLKEM_PT(2) MLKEM_PT(3) MLKEM_PT(4) MLKEM_PT(5) MLKEM_PT(6) MLKEM_PT(7)
         MLKEM_PT(8) MLKEM_PT(9) MLKEM_PT(10) MLKEM_PT(11) MLKEM_PT(12) MLKEM_PT(13)
 #undef MLKEM_PT
@@ -578,8 +726,8 @@ __global__ void __launch_bounds__(WAVE) k_sample(SampleArgs a) {
 #undef MLKEM_OW
         if (__ballot(eta == 3) != 0) {   // eta = 3 needs 192 bytes: the rest of this block + the head of the next
             const bool mine = g < a.n_prf && eta == 3;
-            if (a.prf_rate == 136) prf_eta3_tail<136>(s, out, mine);
-            else prf_eta3_tail<168>(s, out, mine);
+            auto out_fn = [out]() { return out; };
+            prf_eta3_tail(s, a.prf_rate == 136 ? 136u : 168u, out_fn, mine);
         }
     }
 }

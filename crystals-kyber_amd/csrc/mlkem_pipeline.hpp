@@ -116,7 +116,7 @@ struct Workspace {
     event_t ev_sample[2] = {nullptr, nullptr}, ev_free[2] = {nullptr, nullptr};
     size_t cap = 0;    // chunk capacity (items) of A / prf / leftover
     size_t hcap = 0;   // h-chunk capacity (items) of the 32-byte arrays
-    int ring = 64;     // sampler LDS ring size (64 or 128 coefficients per lane)
+    int ring = 64;     // sampler LDS ring size (32, 64 or 128 coefficients per lane); measured equal on MI355X (power-capped)
     int fips = 0;      // 0: bit-identical to the reference (PRF, J on SHAKE128; no-op modulus check)
                        // 1: FIPS 203 conformant (PRF, J on SHAKE256; encaps reports status -4 for t-hat coefficients >= q)
     Workspace view(int b) const {
@@ -176,6 +176,7 @@ inline void launch_sample(stream_t st, const ParamSet& p, size_t n, const uint8_
     zero_u32(st, ws.leftover);
     const size_t grid = a.xof_blocks + ceil_div(a.n_prf, WAVE);
     if (ws.ring == 128) launch("k_sample_main", k_sample_main<128>, grid, WAVE, st, a);
+    else if (ws.ring == 32) launch("k_sample_main", k_sample_main<32>, grid, WAVE, st, a);
     else launch("k_sample_main", k_sample_main<64>, grid, WAVE, st, a);
     // leftovers: expected 0.8 % of the sponges; the grid covers 1/16 of them and strides over the rest if ever needed
     SampleArgs t = a;
@@ -341,7 +342,10 @@ inline int prf_launch(stream_t st, int eta, size_t n, const uint8_t* in33, uint8
 }
 inline int hash_launch(stream_t st, int kind, size_t n, const uint8_t* msg, unsigned len, size_t stride, uint8_t* out) {
     if (kind < 0 || kind > 2 || (stride & 7) || stride < len) return -1;   // rows must start 8-byte aligned
-    launch("k_hash_batch", k_hash_batch, ceil_div(n, WAVE), WAVE, st, n, kind, msg, len, stride, out);
+    const size_t grid = ceil_div(n, WAVE);
+    if (kind == 0) launch("k_hash_batch", k_hash_batch<0>, grid, WAVE, st, n, msg, len, stride, out);
+    else if (kind == 1) launch("k_hash_batch", k_hash_batch<1>, grid, WAVE, st, n, msg, len, stride, out);
+    else launch("k_hash_batch", k_hash_batch<2>, grid, WAVE, st, n, msg, len, stride, out);
     return 0;
 }
 

@@ -106,9 +106,24 @@ __device__ __forceinline__ void ring_flush_own(const int16_t* myring, uint16_t* 
     MLKEM_G(T, 30, 2, 4) MLKEM_G(T, 33, 0, 4) MLKEM_G(T, 36, 0, 4) MLKEM_G(T, 39, 0, 4)                     \
     MLKEM_FLUSH()
 
+// RING = 32: a flush point after every 8 triples (16 candidates): at most 15 coefficients are pending after a flush
+// point, so the 32-slot ring never wraps onto unflushed data.  5 KB of LDS per wave instead of 9 KB.
+#define MLKEM_BLOCK32(T)                                                        \
+    MLKEM_G(T, 0, 0, 4) MLKEM_G(T, 3, 0, 4) MLKEM_FLUSH()                       \
+    MLKEM_G(T, 6, 0, 4) MLKEM_G(T, 9, 0, 4) MLKEM_FLUSH()                       \
+    MLKEM_G(T, 12, 0, 4) MLKEM_G(T, 15, 0, 4) MLKEM_FLUSH()                     \
+    MLKEM_G(T, 18, 0, 4) MLKEM_G(T, 21, 0, 4) MLKEM_FLUSH()                     \
+    MLKEM_G(T, 24, 0, 4) MLKEM_G(T, 27, 0, 4) MLKEM_FLUSH()                     \
+    MLKEM_G(T, 30, 0, 4) MLKEM_G(T, 33, 0, 4) MLKEM_FLUSH()                     \
+    MLKEM_G(T, 36, 0, 4) MLKEM_G(T, 39, 0, 4) MLKEM_FLUSH()
+#define MLKEM_SQUEEZE(T)                                  \
+    if constexpr (R::N == 32) { MLKEM_BLOCK32(T) }        \
+    else { MLKEM_BLOCK(T) }
+
 template <int RING_N>
-__global__ void __launch_bounds__(WAVE) k_sample_main(SampleArgs a) {
+__global__ void __launch_bounds__(WAVE, MLKEM_KECCAK_MINWAVES) k_sample_main(SampleArgs a) {
     using R = RingCfg<RING_N>;
+    static_assert(WAVE * R::STRIDE * 2 >= 32 * 33 * 4, "the PRF role stages 32 rows x 33 dwords in the ring");
     __shared__ __attribute__((aligned(16))) int16_t ring[WAVE * R::STRIDE];
     const int l = lane_id();
     KeccakState s;
@@ -130,11 +145,11 @@ __global__ void __launch_bounds__(WAVE) k_sample_main(SampleArgs a) {
         keccak_xor_byte<34>(s, 0x1F);
         keccak_xor_byte<167>(s, 0x80);
         keccak_f1600(s);
-        MLKEM_BLOCK(MLKEM_T_FAST)
+        MLKEM_SQUEEZE(MLKEM_T_FAST)
         keccak_f1600(s);
-        MLKEM_BLOCK(MLKEM_T_FAST)
+        MLKEM_SQUEEZE(MLKEM_T_FAST)
         keccak_f1600(s);
-        MLKEM_BLOCK(MLKEM_T_GUARD)
+        MLKEM_SQUEEZE(MLKEM_T_GUARD)
         if (cnt < 256 && g < a.n_xof) {   // ~0.8 % of sponges: finished by k_sample in list mode
             const uint32_t idx = atomicAdd(&a.leftover[0], 1u);
             a.leftover[1 + idx] = (uint32_t)g;
@@ -155,31 +170,44 @@ __global__ void __launch_bounds__(WAVE) k_sample_main(SampleArgs a) {
         if (a.prf_rate == 136) keccak_xor_byte<135>(s, 0x80);   // SHAKE256 (FIPS 203 mode)
         else keccak_xor_byte<167>(s, 0x80);                     // SHAKE128 (the reference: ml_kem.c:508)
         keccak_f1600(s);
-        // stage the 128 (or 168) bytes of every lane in LDS and write them out as 16 B per lane, 8 lanes per row
-        uint32_t* st32 = reinterpret_cast<uint32_t*>(ring);   // 64 rows x 33 dwords (odd stride: conflict-free)
-#define MLKEM_SW(W) st32[l * 33 + W] = keccak_word<W>(s);
-        MLKEM_SW(0) MLKEM_SW(1) MLKEM_SW(2) MLKEM_SW(3) MLKEM_SW(4) MLKEM_SW(5) MLKEM_SW(6) MLKEM_SW(7)
-        MLKEM_SW(8) MLKEM_SW(9) MLKEM_SW(10) MLKEM_SW(11) MLKEM_SW(12) MLKEM_SW(13) MLKEM_SW(14) MLKEM_SW(15)
-        MLKEM_SW(16) MLKEM_SW(17) MLKEM_SW(18) MLKEM_SW(19) MLKEM_SW(20) MLKEM_SW(21) MLKEM_SW(22) MLKEM_SW(23)
-        MLKEM_SW(24) MLKEM_SW(25) MLKEM_SW(26) MLKEM_SW(27) MLKEM_SW(28) MLKEM_SW(29) MLKEM_SW(30) MLKEM_SW(31)
-#undef MLKEM_SW
-        wave_lds_fence();
+        // stage the first 128 bytes of every lane in LDS, 32 lanes at a time (32 rows x 33 dwords: odd stride,
+        // conflict-free, 4.2 KB), and write them out as 16 B per lane, 8 lanes per row
+        uint32_t* st32 = reinterpret_cast<uint32_t*>(ring);
         const size_t g0 = g - (size_t)l;
-#pragma unroll
-        for (int it = 0; it < 8; it++) {
-            const int f = it * WAVE + l, row = f >> 3, q = f & 7;   // row = lane whose output is written, q = 16-byte piece
-            if (g0 + row < a.n_prf) {
-                uint4 v;
-                v.x = st32[row * 33 + 4 * q]; v.y = st32[row * 33 + 4 * q + 1];
-                v.z = st32[row * 33 + 4 * q + 2]; v.w = st32[row * 33 + 4 * q + 3];
-                *reinterpret_cast<uint4*>(a.prf + (g0 + row) * a.prf_stride + 16 * q) = v;
+#pragma unroll 1
+        for (int half = 0; half < 2; half++) {
+            if ((l >> 5) == half) {
+                uint32_t* mine = st32 + (l & 31) * 33;
+#define MLKEM_SW(W) mine[W] = keccak_word<W>(s);
+                MLKEM_SW(0) MLKEM_SW(1) MLKEM_SW(2) MLKEM_SW(3) MLKEM_SW(4) MLKEM_SW(5) MLKEM_SW(6) MLKEM_SW(7)
+                MLKEM_SW(8) MLKEM_SW(9) MLKEM_SW(10) MLKEM_SW(11) MLKEM_SW(12) MLKEM_SW(13) MLKEM_SW(14) MLKEM_SW(15)
+                MLKEM_SW(16) MLKEM_SW(17) MLKEM_SW(18) MLKEM_SW(19) MLKEM_SW(20) MLKEM_SW(21) MLKEM_SW(22) MLKEM_SW(23)
+                MLKEM_SW(24) MLKEM_SW(25) MLKEM_SW(26) MLKEM_SW(27) MLKEM_SW(28) MLKEM_SW(29) MLKEM_SW(30) MLKEM_SW(31)
+#undef MLKEM_SW
             }
+            wave_lds_fence();
+#pragma unroll
+            for (int it = 0; it < 4; it++) {
+                const int f = it * WAVE + l, row = f >> 3, q = f & 7;   // row = staged lane (0..31), q = 16-byte piece
+                const size_t gi = g0 + (size_t)(32 * half + row);
+                if (gi < a.n_prf) {
+                    uint4 v;
+                    v.x = st32[row * 33 + 4 * q]; v.y = st32[row * 33 + 4 * q + 1];
+                    v.z = st32[row * 33 + 4 * q + 2]; v.w = st32[row * 33 + 4 * q + 3];
+                    *reinterpret_cast<uint4*>(a.prf + gi * a.prf_stride + 16 * q) = v;
+                }
+            }
+            wave_lds_fence();
         }
         if (__ballot(eta == 3) != 0) {   // eta = 3: the rest of this block + the head of the next (192 bytes in all)
-            uint32_t* out = reinterpret_cast<uint32_t*>(a.prf + gc * a.prf_stride);
             const bool mine = g < a.n_prf && eta == 3;
-            if (a.prf_rate == 136) prf_eta3_tail<136>(s, out, mine);
-            else prf_eta3_tail<168>(s, out, mine);
+            // the output row is recomputed from a fresh lane id after the permutation: nothing but the state is live
+            // across it, which keeps the kernel inside its register budget (MLKEM_KECCAK_MINWAVES)
+            auto out_fn = [&a]() {
+                const size_t g2 = (size_t)(blockIdx.x - a.xof_blocks) * WAVE + lane_id_fresh();
+                return reinterpret_cast<uint32_t*>(a.prf + (g2 < a.n_prf ? g2 : a.n_prf - 1) * a.prf_stride);
+            };
+            prf_eta3_tail(s, a.prf_rate == 136 ? 136u : 168u, out_fn, mine);
         }
     }
 }

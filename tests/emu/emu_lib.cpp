@@ -40,7 +40,7 @@ static void free_ws(Workspace& ws) {
 }
 
 extern "C" {
-void emu_config(size_t cap, size_t hcap, int ring) { g_cap = cap; g_hcap = hcap; g_ring = ring == 128 ? 128 : 64; }
+void emu_config(size_t cap, size_t hcap, int ring) { g_cap = cap; g_hcap = hcap; g_ring = (ring == 128 || ring == 32) ? ring : 64; }
 void emu_conformance(int fips) { g_fips = fips != 0; }
 int emu_keygen(int set, size_t n, const uint8_t* d, const uint8_t* z, uint8_t* ek, uint8_t* dk) {
     Workspace ws = make_ws(n);

@@ -103,7 +103,35 @@ def test_emu_kem_matches_oracle_and_golden(emu, oracle, golden, pset):
     assert (Kd[1] == K[1]).all() and (Kd[4] == K[4]).all() and not (Kd[3] == K[3]).all()
 
 
-@pytest.mark.parametrize("ring", (64, 128))
+@pytest.mark.parametrize("pset", (512, 768, 1024))
+def test_emu_full_wave_hash_kernels_take_the_dma_staging(emu, oracle, pset):
+    """64 + 3 items: the first wave of k_hash_encaps / k_hash_decaps / k_hash_keygen_fin is complete, so its sponges are
+    fed by the LDS-DMA staging (one- and two-segment messages, partial last column at ML-KEM-512: 800 = 5*136 + 120);
+    the second, ragged wave takes the synchronous staging.  Both must agree with the oracle."""
+    ekl, dkl, cl = SIZES[pset]
+    n = 67
+    d, z, m = seeds("emu-fw-d", n, pset), seeds("emu-fw-z", n, pset), seeds("emu-fw-m", n, pset)
+    ek, dk = np.zeros((n, ekl), np.uint8), np.zeros((n, dkl), np.uint8)
+    assert emu.emu_keygen(pset, C.c_size_t(n), p8(d), p8(z), p8(ek), p8(dk)) == 0
+    ek_o, dk_o = oracle.keygen(pset, d, z)
+    assert (ek == ek_o).all() and (dk == dk_o).all()
+    c, K = np.zeros((n, cl), np.uint8), np.zeros((n, 32), np.uint8)
+    assert emu.emu_encaps(pset, C.c_size_t(n), p8(ek), p8(m), p8(c), p8(K), None) == 0
+    c_o, K_o = oracle.encaps(pset, ek, m)
+    assert (c == c_o).all() and (K == K_o).all()
+    cb, dkb = c.copy(), dk.copy()
+    cb[[0, 17, 63, 66], [3, cl - 1, 100, 7]] ^= 4      # implicit rejection: K = J(z || c) from the DMA-fed sponge
+    dkb[[5, 64], dkl - 40] ^= 1                        # stored H(ek) corrupted -> -5
+    Kd, st = np.zeros((n, 32), np.uint8), np.zeros(n, np.int32)
+    assert emu.emu_decaps(pset, C.c_size_t(n), p8(dkb), p8(cb), p8(Kd), st.ctypes.data_as(C.POINTER(C.c_int32)), 1) == 0
+    Ko, sto = oracle.decaps(pset, dkb, cb)
+    assert (st == sto).all() and sorted(np.nonzero(st)[0].tolist()) == [5, 64]
+    assert (Kd[sto == 0] == Ko[sto == 0]).all()
+    for i in (0, 17, 63, 66):
+        assert not (Kd[i] == K[i]).all()
+
+
+@pytest.mark.parametrize("ring", (32, 64, 128))
 def test_emu_matrix_sampler_with_leftover_pass(emu, oracle, ring):
     """Production SampleNTT path: three-block main kernel + general kernel over the leftover list.  With 576
     sponges about 0.8 % (4-5) need a 4th squeeze block; the test requires that the leftover path was taken."""

@@ -347,7 +347,7 @@ def test_ml_kem_h_dropin_shim(pkg, tmp_path):
     assert "Type check failed" in r.stderr and "Hash check failed" in r.stderr
 
 
-@pytest.mark.parametrize("env", ({"MLKEM_OVERLAP": "1"}, {"MLKEM_RING": "128"}, {"MLKEM_HCHUNK_ITEMS": "300"}))
+@pytest.mark.parametrize("env", ({"MLKEM_OVERLAP": "1"}, {"MLKEM_RING": "128"}, {"MLKEM_RING": "32"}, {"MLKEM_HCHUNK_ITEMS": "300"}))
 def test_engine_options_do_not_change_results(pkg, torch, oracle, env, monkeypatch):
     """Opt-in execution modes read at context creation: two-stream sampler/arithmetic overlap, the 128-coefficient
     sampler ring, small h-chunks.  Same bytes out."""
