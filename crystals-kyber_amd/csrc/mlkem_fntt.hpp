@@ -26,6 +26,36 @@ __device__ __forceinline__ float fred(float x) {
 }
 // zeta * b mod q (centred), |zeta * b| <= 2^24
 __device__ __forceinline__ float fmulmod(float zeta, float b) { return fred(zeta * b); }
+// The same for a CONSTANT multiplier whose quotient zq = fl(zeta / q) is precomputed (Shoup's trick on the fp32 pipe):
+//   kM  = fma(b, zq, M)          = M + k,  k = rint(b zeta / q) up to the usual off-by-one near .5   (exact: |k| < 2^22)
+//   nkq = fma(kM, -q, M q)       = -k q    exact: M q = 9987 * 2^22 is a float, |k q| <= 2^24 (k q is even if it is larger)
+//   t   = fma(b, zeta, nkq)      = b zeta - k q,  |t| <= 1665
+// Three dependent FMAs instead of mul + 3 (fred): one VALU instruction less per butterfly (fmulmod_shoup).
+constexpr float F_MAGIC_Q = 12582912.0f * 3329.0f;   // exactly representable (9987 * 2^22)
+struct Tw {
+    float z, zq;   // zeta (centred) and fl(zeta / q)
+};
+__device__ __forceinline__ float fmulmod_shoup(Tw w, float b) {
+    const float km = __builtin_fmaf(b, w.zq, F_MAGIC);
+    const float nkq = __builtin_fmaf(km, -F_Q, F_MAGIC_Q);
+    return __builtin_fmaf(b, w.z, nkq);
+}
+// Measured on MI355X: the 3-FMA form removes 6.5 % of the arithmetic kernels' VALU instructions
+// but needs the (zeta, zeta/q) pairs in registers (+10..18 VGPRs) and the kernels get 3-5 % SLOWER in the power-capped
+// full pass; the NTT-only kernels do not change.  It is therefore compiled in only with MLKEM_TW3=1; the default keeps
+// mul + Barrett (the quotient halves of the twiddle pairs are dead code then).
+#ifndef MLKEM_TW3
+#define MLKEM_TW3 0
+#endif
+__device__ __forceinline__ float fmulmod(Tw w, float b) {
+#if MLKEM_TW3
+    return fmulmod_shoup(w, b);
+#else
+    return fred(w.z * b);
+#endif
+}
+constexpr Tw tw_const(int zeta_centred) { return Tw{(float)zeta_centred, (float)((double)zeta_centred / 3329.0)}; }
+__device__ __forceinline__ Tw tw_neg(Tw w) { return Tw{-w.z, -w.zq}; }
 // canonical representative in [0, q) as an integer, for |x| <= 2^24
 __device__ __forceinline__ int fcanon(float x) {
     float r = fred(x);
@@ -34,20 +64,20 @@ __device__ __forceinline__ int fcanon(float x) {
 }
 
 struct ZetaTableF {
-    float z[128];
+    Tw z[128];
     constexpr ZetaTableF() : z{} {
-        for (int i = 0; i < 128; i++) z[i] = (float)cx_centered(cx_pow17(cx_bitrev7(i)));
+        for (int i = 0; i < 128; i++) z[i] = tw_const(cx_centered(cx_pow17(cx_bitrev7(i))));
     }
 };
 __device__ const ZetaTableF ZETA_F = ZetaTableF();   // zeta_i = 17^BitRev7(i) mod q, centred (ml_kem.c:300-307)
 
 struct NttTwiddlesF {
-    float fB0, fB1, fB2, fC0, fC1, fC2, fD;   // forward: see NttTwiddles in mlkem_device.hpp for the index map
-    float iD, iC0, iC1, iC2, iB0, iB1, iB2;   // inverse
+    Tw fB0, fB1, fB2, fC0, fC1, fC2, fD;   // forward: see NttTwiddles in mlkem_device.hpp for the index map
+    Tw iD, iC0, iC1, iC2, iB0, iB1, iB2;   // inverse
 };
 __device__ __forceinline__ void load_twiddles_f(NttTwiddlesF& t) {
     const int l = lane_id(), blk = l >> 4, b16 = l >> 2;
-    const float* z = ZETA_F.z;
+    const Tw* z = ZETA_F.z;
     t.fB0 = z[4 + blk]; t.fB1 = z[8 + 2 * blk]; t.fB2 = z[9 + 2 * blk];
     t.fC0 = z[16 + b16]; t.fC1 = z[32 + 2 * b16]; t.fC2 = z[33 + 2 * b16];
     t.fD = z[64 + l];
@@ -55,19 +85,19 @@ __device__ __forceinline__ void load_twiddles_f(NttTwiddlesF& t) {
     t.iC0 = z[63 - 2 * b16]; t.iC1 = z[62 - 2 * b16]; t.iC2 = z[31 - b16];
     t.iB0 = z[15 - 2 * blk]; t.iB1 = z[14 - 2 * blk]; t.iB2 = z[7 - blk];
 }
-constexpr float FZ1 = (float)cx_centered(cx_pow17(cx_bitrev7(1)));
-constexpr float FZ2 = (float)cx_centered(cx_pow17(cx_bitrev7(2)));
-constexpr float FZ3 = (float)cx_centered(cx_pow17(cx_bitrev7(3)));
-constexpr float F_INV128 = (float)(INV128 - KQ);   // 128^-1 = 3303 = -26 mod q (ml_kem.c:378-381)
+constexpr Tw FZ1 = tw_const(cx_centered(cx_pow17(cx_bitrev7(1))));
+constexpr Tw FZ2 = tw_const(cx_centered(cx_pow17(cx_bitrev7(2))));
+constexpr Tw FZ3 = tw_const(cx_centered(cx_pow17(cx_bitrev7(3))));
+constexpr Tw F_INV128 = tw_const(INV128 - KQ);   // 128^-1 = 3303 = -26 mod q (ml_kem.c:378-381)
 
 // Cooley-Tukey (ml_kem.c:311-324): a' = a + zeta b, b' = a - zeta b ; bounds grow by 1665 per layer
-__device__ __forceinline__ void ct_bfly_f(float& a, float& b, float zeta) {
+__device__ __forceinline__ void ct_bfly_f(float& a, float& b, Tw zeta) {
     const float t = fmulmod(zeta, b);
     b = a - t;
     a = a + t;
 }
 // Gentleman-Sande (ml_kem.c:359-373): a' = a + b, b' = zeta (b - a)
-__device__ __forceinline__ void gs_bfly_f(float& a, float& b, float zeta) {
+__device__ __forceinline__ void gs_bfly_f(float& a, float& b, Tw zeta) {
     const float t = a;
     a = t + b;
     b = fmulmod(zeta, b - t);
@@ -174,7 +204,7 @@ __device__ __forceinline__ void stash_vhat_f(float* vh, float* vg, const float (
     fx_write4(vh, 4 * l, x);
     float2 g;
     g.x = fmulmod(tw.fD, x[1]);
-    g.y = fmulmod(-tw.fD, x[3]);
+    g.y = fmulmod(tw_neg(tw.fD), x[3]);
     *reinterpret_cast<float2*>(vg + 2 * l) = g;
 }
 // acc = (acc + a o v) reduced : for 0 <= a <= 4095 (raw 12-bit, F3) and |v|, |acc| <= 1665 the exact sum is

@@ -121,7 +121,7 @@ __device__ __forceinline__ void ring_flush_own(const int16_t* myring, uint16_t* 
     else { MLKEM_BLOCK(T) }
 
 template <int RING_N>
-__global__ void __launch_bounds__(WAVE, MLKEM_KECCAK_MINWAVES) k_sample_main(SampleArgs a) {
+__global__ void __launch_bounds__(WAVE, (RING_N == 32 ? MLKEM_KECCAK_MINWAVES : RING_N == 64 ? 4 : 2)) k_sample_main(SampleArgs a) {   // LDS caps rings 64 / 128 at 4 / 2 waves per SIMD
     using R = RingCfg<RING_N>;
     static_assert(WAVE * R::STRIDE * 2 >= 32 * 33 * 4, "the PRF role stages 32 rows x 33 dwords in the ring");
     __shared__ __attribute__((aligned(16))) int16_t ring[WAVE * R::STRIDE];

@@ -87,4 +87,25 @@ int emu_sample_matrix(int k, size_t n, const uint8_t* rho, int transpose, uint16
     free_ws(ws);
     return left;
 }
+// Exhaustive check of the product's 3-FMA constant-multiplier modular product (mlkem_fntt.hpp: fmulmod_shoup) over every
+// twiddle the NTT uses (+/- the 128 zetas, 128^-1) and every integer |b| <= 10082: result must be congruent to
+// zeta*b mod q and centred (|t| <= 1665).  Returns the number of violations.
+long emu_fmulmod_exhaustive(void) {
+    long bad = 0;
+    for (int i = 0; i <= 128; i++) {
+        for (int sign = -1; sign <= 1; sign += 2) {
+            Tw w = i < 128 ? ZETA_F.z[i] : F_INV128;
+            if (sign < 0) w = tw_neg(w);
+            const long z = (long)w.z;
+            for (int b = -10082; b <= 10082; b++) {
+                const float t = fmulmod_shoup(w, (float)b);
+                const long ti = (long)t;
+                if ((float)ti != t || ti > 1665 || ti < -1665 || ((z * b - ti) % KQ) != 0) bad++;
+                const float t2 = fmulmod(w.z, (float)b);          // the generic 4-instruction form agrees mod q
+                if ((((long)t2 - ti) % KQ) != 0) bad++;
+            }
+        }
+    }
+    return bad;
+}
 }

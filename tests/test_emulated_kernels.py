@@ -42,6 +42,12 @@ def test_emu_ntt_intt_multiply(emu, oracle, golden_npz):
     assert (out == golden_npz["nc_ab_mul"][:4]).all()
 
 
+def test_emu_fp32_twiddle_product_exhaustive(emu):
+    """Every (twiddle, b) pair the NTT can meet: 258 multipliers x 20165 values through the product's 3-FMA modular product."""
+    emu.emu_fmulmod_exhaustive.restype = C.c_long
+    assert emu.emu_fmulmod_exhaustive() == 0
+
+
 def test_emu_sampling(emu, oracle, golden_npz):
     s = golden_npz["g2_in"].copy()
     out = np.zeros((s.shape[0], 256), np.uint16)
