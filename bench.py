@@ -303,6 +303,15 @@ def main():
         roofline["traffic"] = t["hbm_bytes_per_step_corrected"]
         roofline["traffic_note"] = "bytes per step from %s: (2*FETCH_SIZE + WRITE_SIZE)*1024; raw = %.3g" % (
             os.path.relpath(tpath, ROOT), t["hbm_bytes_per_step_raw"])
+    if args.workload != "ntt" and dom == "k_sample_main":
+        # the dominant kernel's own HBM bytes per launch: per item it reads rho and r (32 B each) and
+        # writes the k x k matrix (512 B per polynomial) and the PRF rows (128 B, 192 B for eta = 3)
+        k = {"kem512": 2, "kem768": 3, "kem1024": 4}[args.workload]
+        per_item = 64 + 512 * k * k + (2 * k + 1) * 128 + (k * 64 if k == 2 else 0)
+        chunk = min(extra.get("chunk_items") or (1 << 18), args.batch)
+        roofline["dominant_kernel_bytes_per_launch"] = per_item * chunk
+        roofline["dominant_kernel_GBps"] = per_item * chunk / (kernels[dom]["ms_avg"] * 1e-3) / 1e9
+        roofline["dominant_kernel_frac"] = roofline["dominant_kernel_GBps"] / HBM_PEAK_GBS
     if args.workload == "kem768":
         # the bound that actually binds: 95 Keccak-f per pair x 24 rounds x 180 VALU (122 full-rate + 58
         # v_alignbit_b32 at ~0.58x rate, profiles/r01_valu_ubench.txt), + NTT / codec / sampling work
@@ -310,7 +319,9 @@ def main():
         roofline["binding"] = {"bound": "valu-int32", "keccak_lane_ops_per_pair": keccak_ops,
                                "keccak_lane_ops_per_s": value / world * keccak_ops,
                                "peak_lane_ops_per_s": VALU_PEAK_LANE_OPS,
-                               "frac_keccak_only": value / world * keccak_ops / VALU_PEAK_LANE_OPS}
+                               "frac_keccak_only": value / world * keccak_ops / VALU_PEAK_LANE_OPS,
+                               "note": "the pass runs into the socket power limit (rocm-smi: ~1340 W, shader clock ~2.07 GHz instead of "
+                                       "2.4 GHz; DESIGN.md section 5, profiles/r01_clock_power_watch.txt, profiles/r01_power_ubench.txt)"}
     line = {"metric": metric, "value": value, "unit": unit, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype,
             "data": "synthetic", "config": {"workload": wl, "batch_per_gpu": args.batch, "parallelism": "shard%d (no collectives)" % world,
