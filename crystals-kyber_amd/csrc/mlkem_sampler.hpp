@@ -46,18 +46,21 @@ __device__ __forceinline__ void ring_flush_t(const int16_t* ring, uint16_t* A, s
     if (has) flushed += R::CHUNK;
 }
 
-// one 3-byte group -> two candidates (ml_kem.c:208-219)
+// one 3-byte group -> two candidates (ml_kem.c:208-219).  `pos` = 2 x (number of accepted coefficients): the ring is
+// addressed in bytes so that accepting costs v_cmp + v_cndmask(0, 2) + one full-rate v_add (an element index would add
+// a slow-class v_lshl_add per candidate for the address).
+#define MLKEM_RING_AT(p) (*reinterpret_cast<int16_t*>(ringb + ((p) & (2u * R::N - 1u))))
 #define MLKEM_T_FAST(v)                                                                   \
     {                                                                                     \
         const uint32_t d1 = (v) & 0xFFFu, d2 = (v) >> 12;                                 \
-        myring[cnt & (R::N - 1)] = (int16_t)d1; cnt += d1 < (uint32_t)KQ ? 1 : 0;         \
-        myring[cnt & (R::N - 1)] = (int16_t)d2; cnt += d2 < (uint32_t)KQ ? 1 : 0;         \
+        MLKEM_RING_AT(pos) = (int16_t)d1; pos += d1 < (uint32_t)KQ ? 2u : 0u;             \
+        MLKEM_RING_AT(pos) = (int16_t)d2; pos += d2 < (uint32_t)KQ ? 2u : 0u;             \
     }
 #define MLKEM_T_GUARD(v)                                                                  \
     {                                                                                     \
         const uint32_t d1 = (v) & 0xFFFu, d2 = (v) >> 12;                                 \
-        if (d1 < (uint32_t)KQ && cnt < 256) { myring[cnt & (R::N - 1)] = (int16_t)d1; cnt++; } \
-        if (d2 < (uint32_t)KQ && cnt < 256) { myring[cnt & (R::N - 1)] = (int16_t)d2; cnt++; } \
+        if (d1 < (uint32_t)KQ && pos < 512u) { MLKEM_RING_AT(pos) = (int16_t)d1; pos += 2u; } \
+        if (d2 < (uint32_t)KQ && pos < 512u) { MLKEM_RING_AT(pos) = (int16_t)d2; pos += 2u; } \
     }
 // triples FIRST..LAST-1 (0..3) of the 12-byte group starting at state dword W0
 #define MLKEM_G(T, W0, FIRST, LAST)                                                                       \
@@ -76,23 +79,28 @@ __device__ __forceinline__ void ring_flush_t(const int16_t* ring, uint16_t* A, s
 #define MLKEM_SAMPLER_COOP_FLUSH 0
 #endif
 template <class R>
-__device__ __forceinline__ void ring_flush_own(const int16_t* myring, uint16_t* A, size_t g, size_t n_xof, int cnt, int& flushed) {
-    if ((cnt - flushed >= R::CHUNK) && (g < n_xof)) {
-        const int16_t* src = myring + (flushed & (R::N - 1));
-        uint16_t* dst = A + g * 256 + flushed;
+__device__ __forceinline__ void ring_flush_own(const char* ringb, uint16_t* A, size_t g, size_t n_xof, uint32_t pos, uint32_t& flushed) {
+    // pos / flushed in bytes (2 per coefficient)
+    if ((pos - flushed >= 2u * R::CHUNK) && (g < n_xof)) {
+        const char* src = ringb + (flushed & (2u * R::N - 1u));
+        char* dst = reinterpret_cast<char*>(A + g * 256) + flushed;
 #pragma unroll
         for (int q = 0; q < R::CHUNK / 8; q++)
             reinterpret_cast<uint4*>(dst)[q] = reinterpret_cast<const uint4*>(src)[q];
-        flushed += R::CHUNK;
+        flushed += 2u * R::CHUNK;
     }
 }
 #if MLKEM_SAMPLER_COOP_FLUSH
-#define MLKEM_FLUSH()                                               \
-    wave_lds_fence();                                               \
-    ring_flush_t<R>(ring, a.A, g, a.n_xof, cnt, flushed);           \
-    wave_lds_fence();
+#define MLKEM_FLUSH()                                                       \
+    {                                                                       \
+        int fl = (int)(flushed >> 1);                                       \
+        wave_lds_fence();                                                   \
+        ring_flush_t<R>(ring, a.A, g, a.n_xof, (int)(pos >> 1), fl);        \
+        wave_lds_fence();                                                   \
+        flushed = (uint32_t)fl << 1;                                        \
+    }
 #else
-#define MLKEM_FLUSH() ring_flush_own<R>(myring, a.A, g, a.n_xof, cnt, flushed);
+#define MLKEM_FLUSH() ring_flush_own<R>(ringb, a.A, g, a.n_xof, pos, flushed);
 #endif
 
 // the 56 triples of one squeezed block, with NFLUSH = 4 (quarters of 14 triples) or 2 (halves of 28) flush points
@@ -136,8 +144,8 @@ __global__ void __launch_bounds__(WAVE, (RING_N == 32 ? MLKEM_KECCAK_MINWAVES : 
         const unsigned e = (unsigned)(gc - item * kk), ra = e / (unsigned)a.K, cb = e - ra * (unsigned)a.K;
         load32(a.rho, a.rho_stride, item, seed);
         const unsigned i0 = a.transpose ? ra : cb, i1 = a.transpose ? cb : ra;
-        int16_t* myring = ring + l * R::STRIDE;
-        int cnt = 0, flushed = 0;
+        char* ringb = reinterpret_cast<char*>(ring + l * R::STRIDE);   // this lane's ring
+        uint32_t pos = 0, flushed = 0;                                 // bytes: 2 x accepted / flushed coefficients
         keccak_zero(s);
         MLKEM_SET_WORDS8(s, 0, seed)
         keccak_xor_byte<32>(s, i0);
@@ -150,7 +158,7 @@ __global__ void __launch_bounds__(WAVE, (RING_N == 32 ? MLKEM_KECCAK_MINWAVES : 
         MLKEM_SQUEEZE(MLKEM_T_FAST)
         keccak_f1600(s);
         MLKEM_SQUEEZE(MLKEM_T_GUARD)
-        if (cnt < 256 && g < a.n_xof) {   // ~0.8 % of sponges: finished by k_sample in list mode
+        if (pos < 512u && g < a.n_xof) {   // ~0.8 % of sponges: finished by k_sample in list mode
             const uint32_t idx = atomicAdd(&a.leftover[0], 1u);
             a.leftover[1 + idx] = (uint32_t)g;
         }

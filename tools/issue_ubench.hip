@@ -19,6 +19,14 @@ __global__ void __launch_bounds__(64) k_issue(uint32_t* out, int iters) {
                 if (OP == 0) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(r[i]) : "v"(r[15]));
                 if (OP == 1) asm volatile("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(r[i]) : "v"(r[15]), "v"(r[14]));
                 if (OP == 2) asm volatile("v_alignbit_b32 %0, %0, %1, 7" : "+v"(r[i]) : "v"(r[15]));
+                if (OP == 3) asm volatile("v_sub_co_u32 %0, vcc, %0, %1" : "+v"(r[i]) : "v"(r[15]) : "vcc");
+                if (OP == 4) asm volatile("v_addc_co_u32 %0, vcc, %0, %1, vcc" : "+v"(r[i]) : "v"(r[15]) : "vcc");
+                if (OP == 5) asm volatile("v_cmp_gt_u32 vcc, %0, %1" : : "v"(r[i]), "v"(r[15]) : "vcc");
+                if (OP == 6) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(r[i]) : "v"(r[15]) : "vcc");
+                if (OP == 7) asm volatile("v_addc_co_u32_e64 %0, s[20:21], %0, 0, s[22:23]" : "+v"(r[i]) : : "s20", "s21", "s22", "s23");
+                if (OP == 8) asm volatile("v_sub_co_u32_e64 %0, s[20:21], %0, %1" : "+v"(r[i]) : "v"(r[15]) : "s20", "s21");
+                if (OP == 9) asm volatile("v_cmp_gt_u32_e64 s[20:21], %0, %1" : : "v"(r[i]), "v"(r[15]) : "s20", "s21");
+                if (OP == 10) asm volatile("v_cndmask_b32_e64 %0, 0, 2, s[22:23]" : "+v"(r[i]) : : "s22", "s23");
             }
         }
     }
@@ -61,5 +69,7 @@ int main() {
     run<1, 0>(out, "v_xor"); run<2, 0>(out, "v_xor"); run<4, 0>(out, "v_xor"); run<8, 0>(out, "v_xor"); run<16, 0>(out, "v_xor");
     run<1, 1>(out, "v_bitop3"); run<2, 1>(out, "v_bitop3"); run<4, 1>(out, "v_bitop3"); run<8, 1>(out, "v_bitop3");
     run<1, 2>(out, "v_alignbit"); run<2, 2>(out, "v_alignbit"); run<4, 2>(out, "v_alignbit"); run<8, 2>(out, "v_alignbit");
+    run<8, 3>(out, "v_sub_co"); run<8, 4>(out, "v_addc_co"); run<8, 5>(out, "v_cmp_gt"); run<8, 6>(out, "v_cndmask");
+    run<8, 7>(out, "addc_e64"); run<8, 8>(out, "sub_co_e64"); run<8, 9>(out, "cmp_e64"); run<8, 10>(out, "cndmask_e64");
     return 0;
 }
