@@ -30,10 +30,12 @@ ABI_SYMBOLS = (
     "mlkem_ntt_dev", "mlkem_intt_dev", "mlkem_multiply_ntts_dev", "mlkem_sample_ntt_dev", "mlkem_sample_cbd_dev",
     "mlkem_prf_dev", "mlkem_hash_dev", "mlkem_keccak_sponge_dev", "mlkem_sha3_pad_bits",
     "mlkem_keygen", "mlkem_encaps", "mlkem_decaps", "mlkem_ntt", "mlkem_intt", "mlkem_keccak_sponge",
+    "mlkem_sample_ntt", "mlkem_sample_cbd",
     "mlkem_keygen_random", "mlkem_encaps_random",
     "mlkem_cells_to_bytes_dev", "mlkem_bytes_to_cells_dev", "mlkem_keygen_stream", "mlkem_encaps_stream", "mlkem_decaps_stream",
 )
-SHIM_SYMBOLS = ("init", "KEM_KeyGen", "KEM_Encaps", "KEM_Decaps", "ml_errno", "sha3_b", "sha3_h", "sha3_s", "h2b", "b2h")
+SHIM_SYMBOLS = ("init", "KEM_KeyGen", "KEM_Encaps", "KEM_Decaps", "ml_errno", "sha3_b", "sha3_h", "sha3_s", "h2b", "b2h",
+                "SampleNTT", "SamplePolyCBD", "NTT", "InverseNTT")
 
 
 class MLKEMError(RuntimeError):

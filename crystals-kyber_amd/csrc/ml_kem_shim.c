@@ -145,6 +145,54 @@ union byte* KEM_Decaps(const struct PARAMS* params, const union byte* dk, unsign
 }
 
 /* ------------------------------------------------------------------------------------------------------------
+ * The four primitives ml_kem.o exports without declaring them (ml_kem.c:189, :253, :287, :336): 4-byte
+ * `union integer` cells in and out, result malloc()ed for the caller, a batch of one on the GPU.  On failure they
+ * print a message, set ml_errno and return NULL (the reference cannot fail here).
+ * ---------------------------------------------------------------------------------------------------------- */
+static union integer* widen_poly(const unsigned short* c) {
+    union integer* f = (union integer*)calloc(256, sizeof(union integer));
+    if (f) for (int i = 0; i < 256; i++) f[i].l = c[i];   /* t = low 12 bits of l: both fields read back the value */
+    return f;
+}
+static void narrow_poly(const union integer* f, unsigned short* c) {
+    for (int i = 0; i < 256; i++) c[i] = (unsigned short)f[i].t;
+}
+union integer* SampleNTT(union byte* B) {   /* ml_kem.c:189-245 */
+    unsigned char seed[34];
+    unsigned short a[256];
+    if (!B) return NULL;
+    for (int i = 0; i < 34; i++) seed[i] = (unsigned char)B[i].e;
+    if (engine_failed("SampleNTT()", mlkem_sample_ntt(1, seed, a))) return NULL;
+    return widen_poly(a);
+}
+union integer* SamplePolyCBD(const union byte* B, unsigned int n) {   /* ml_kem.c:253-275 */
+    unsigned char bytes[192];
+    unsigned short f[256];
+    if (!B || (n != 2 && n != 3)) {
+        report("SamplePolyCBD()", "eta must be 2 or 3");
+        ml_errno = MLKEM_ERR_ARG;
+        return NULL;
+    }
+    for (unsigned i = 0; i < 64 * n; i++) bytes[i] = (unsigned char)B[i].e;
+    if (engine_failed("SamplePolyCBD()", mlkem_sample_cbd((int)n, 1, bytes, f))) return NULL;
+    return widen_poly(f);
+}
+union integer* NTT(const union integer* f) {   /* ml_kem.c:287-329 */
+    unsigned short in[256], out[256];
+    if (!f) return NULL;
+    narrow_poly(f, in);
+    if (engine_failed("NTT()", mlkem_ntt(1, in, out))) return NULL;
+    return widen_poly(out);
+}
+union integer* InverseNTT(const union integer* fh) {   /* ml_kem.c:336-384 */
+    unsigned short in[256], out[256];
+    if (!fh) return NULL;
+    narrow_poly(fh, in);
+    if (engine_failed("InverseNTT()", mlkem_intt(1, in, out))) return NULL;
+    return widen_poly(out);
+}
+
+/* ------------------------------------------------------------------------------------------------------------
  * sha3.h front-ends: same signatures, cell types and ownership as sha3.c:329-494.  Bit fiddling
  * (hex <-> bits, suffix, pad10*1) happens here on the host; the sponge itself runs on the GPU through
  * mlkem_keccak_sponge (a batch of one).  Failures (unsupported capacity, no device) print a message and return NULL.

@@ -448,6 +448,35 @@ static int host_ntt(bool inverse, size_t n, const uint16_t* in, uint16_t* out) {
 int mlkem_ntt(size_t n, const uint16_t* f, uint16_t* fh) { return host_ntt(false, n, f, fh); }
 int mlkem_intt(size_t n, const uint16_t* fh, uint16_t* f) { return host_ntt(true, n, fh, f); }
 
+int mlkem_sample_ntt(size_t n, const uint8_t* seeds34, uint16_t* a_hat) {
+    if (n && (!seeds34 || !a_hat)) return MLKEM_ERR_ARG;
+    std::lock_guard<std::mutex> lock(g_host_mu);
+    mlkem_ctx* ctx;
+    int rc = host_ctx(&ctx);
+    if (rc) return rc;
+    if (n == 0) return MLKEM_OK;
+    DevBuf bi, bo;
+    if ((rc = bi.alloc(n * 34)) || (rc = bo.alloc(n * 512))) return rc;
+    HIP_TRY(hipMemcpy(bi.p, seeds34, n * 34, hipMemcpyHostToDevice));
+    if ((rc = mlkem_sample_ntt_dev(ctx, n, bi.as<uint8_t>(), bo.as<uint16_t>(), nullptr))) return rc;
+    HIP_TRY(hipMemcpy(a_hat, bo.p, n * 512, hipMemcpyDeviceToHost));
+    return MLKEM_OK;
+}
+int mlkem_sample_cbd(int eta, size_t n, const uint8_t* bytes, uint16_t* f) {
+    if ((eta != 2 && eta != 3) || (n && (!bytes || !f))) return MLKEM_ERR_ARG;
+    std::lock_guard<std::mutex> lock(g_host_mu);
+    mlkem_ctx* ctx;
+    int rc = host_ctx(&ctx);
+    if (rc) return rc;
+    if (n == 0) return MLKEM_OK;
+    DevBuf bi, bo;
+    if ((rc = bi.alloc(n * 64 * (size_t)eta)) || (rc = bo.alloc(n * 512))) return rc;
+    HIP_TRY(hipMemcpy(bi.p, bytes, n * 64 * (size_t)eta, hipMemcpyHostToDevice));
+    if ((rc = mlkem_sample_cbd_dev(ctx, eta, n, bi.as<uint8_t>(), bo.as<uint16_t>(), nullptr))) return rc;
+    HIP_TRY(hipMemcpy(f, bo.p, n * 512, hipMemcpyDeviceToHost));
+    return MLKEM_OK;
+}
+
 int mlkem_keccak_sponge(unsigned rate, size_t n, const uint8_t* padded, unsigned nblocks, uint8_t* out, unsigned outlen) {
     if (n && (!padded || !out)) return MLKEM_ERR_ARG;
     std::lock_guard<std::mutex> lock(g_host_mu);

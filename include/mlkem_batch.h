@@ -128,6 +128,10 @@ int mlkem_encaps(int param_set, size_t n, const uint8_t* ek, const uint8_t* m, u
 int mlkem_decaps(int param_set, size_t n, const uint8_t* dk, const uint8_t* c, uint8_t* K, int32_t* status);
 int mlkem_ntt(size_t n, const uint16_t* f, uint16_t* f_hat);
 int mlkem_intt(size_t n, const uint16_t* f_hat, uint16_t* f);
+/* SampleNTT (ml_kem.c:189-245) and SamplePolyCBD (ml_kem.c:253-275) over host buffers: n x 34 seed bytes /
+ * n x 64*eta bytes -> n x uint16[256].  They back the reference's externally visible primitives in the drop-in shim. */
+int mlkem_sample_ntt(size_t n, const uint8_t* seeds34, uint16_t* a_hat);
+int mlkem_sample_cbd(int eta, size_t n, const uint8_t* bytes, uint16_t* f);
 int mlkem_keccak_sponge(unsigned rate, size_t n, const uint8_t* padded, unsigned nblocks, uint8_t* out, unsigned outlen);
 
 /* ---- layout converters and streaming front-end --------------------------------------------------

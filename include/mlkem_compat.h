@@ -73,6 +73,24 @@ union hex* b2h(const union bit* S, unsigned int n);
 union bit* sha3_b(const union bit* bstr, unsigned int n, unsigned int d, unsigned int c, union bit sfx[4]);
 union hex* sha3_h(const union hex* hstr, unsigned int m, unsigned int d, unsigned int c, union bit sfx[4]);
 unsigned char* sha3_s(const char* cstr, unsigned int m, unsigned int d, unsigned int c, union bit sfx[4]);
+/* ---- primitives the reference's objects export without declaring them (`nm ml_kem.o` shows T SampleNTT,
+ * SamplePolyCBD, NTT, InverseNTT; its own test programs Test_Archive/SampleNTT_test06.c, SampleCBD_test07.c and
+ * NTT_test08.c call them).  `union integer` (ml_kem.c:20-23) is a 4-byte cell like `union byte`: the coefficient is
+ * the 12-bit field `t` in bits 0-11; inputs are read through `t` (mod 2^12), outputs are canonical in [0, q).
+ *   symbol          replaced definition     in -> out (malloc()ed for the caller)
+ *   SampleNTT       ml_kem.c:189-245        B[34] cells -> 256 cells     (the caller's B is NOT touched: the reference
+ *                                           bumps B[32], B[33] on its 279-triple retry, probability < 2^-200)
+ *   SamplePolyCBD   ml_kem.c:253-275        B[64 n] cells, n = eta in {2, 3} -> 256 cells
+ *   NTT             ml_kem.c:287-329        256 cells -> 256 cells
+ *   InverseNTT      ml_kem.c:336-384        256 cells -> 256 cells */
+union integer {
+    unsigned int t : 12;
+    unsigned int l : 24;
+};
+union integer* SampleNTT(union byte* B);
+union integer* SamplePolyCBD(const union byte* B, unsigned int n);
+union integer* NTT(const union integer* f);
+union integer* InverseNTT(const union integer* fh);
 struct PKE KEM_KeyGen(const struct PARAMS* params);
 struct KEM KEM_Encaps(const struct PARAMS* params, const union byte* ek, unsigned int ek_len);
 union byte* KEM_Decaps(const struct PARAMS* params, const union byte* dk, unsigned int dk_len, const union byte* c,

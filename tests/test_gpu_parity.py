@@ -347,6 +347,74 @@ def test_ml_kem_h_dropin_shim(pkg, tmp_path):
     assert "Type check failed" in r.stderr and "Hash check failed" in r.stderr
 
 
+PRIM_TEST_C = r"""
+/* The recipes of the reference's own primitive tests (Test_Archive/SampleNTT_test06.c, SampleCBD_test07.c,
+ * NTT_test08.c), written against the symbols ml_kem.o exports: SampleNTT / SamplePolyCBD / NTT / InverseNTT. */
+#include "mlkem_compat.h"
+#include <stdio.h>
+#include <stdlib.h>
+int main(void) {
+    union byte B[192];
+    /* test08: B[i] = 2 i ; f1 = SampleNTT(B) ; fh = NTT(f1) ; f2 = InverseNTT(fh) ; f1 == f2 */
+    for (int i = 0; i < 34; i++) { B[i].e = i * 2; }
+    B[3].s = B[3].s;                               /* both views of the cell alias bits 0.. */
+    union integer* f1 = SampleNTT(B);
+    union integer* fh = NTT(f1);
+    union integer* f2 = InverseNTT(fh);
+    if (!f1 || !fh || !f2) return 2;
+    for (int i = 0; i < 256; i++) if (f1[i].t != f2[i].t) { printf("ERROR :: f1[%d] = %d :: f2[%d] = %d\n", i, f1[i].t, i, f2[i].t); return 3; }
+    printf("f1"); for (int i = 0; i < 8; i++) printf(" %d", f1[i].t); printf("\n");
+    printf("fh"); for (int i = 0; i < 8; i++) printf(" %d", fh[i].t); printf("\n");
+    for (int i = 0; i < 34; i++) if (B[i].e != (unsigned)(i * 2)) return 4;   /* input untouched */
+    free(f1); free(fh); free(f2);
+    /* test06: B[i] = it*i + i, it = 0..6 */
+    for (int it = 0; it < 7; it++) {
+        for (int i = 0; i < 34; i++) B[i].e = it * i + i;
+        union integer* a = SampleNTT(B);
+        if (!a) return 5;
+        printf("s%d", it); for (int i = 0; i < 256; i++) printf(" %d", a[i].t); printf("\n");
+        free(a);
+    }
+    /* test07: B[i] = i, eta = 3 (and eta = 2) */
+    for (int i = 0; i < 192; i++) B[i].e = i;
+    for (unsigned eta = 3; eta >= 2; eta--) {
+        union integer* f = SamplePolyCBD(B, eta);
+        if (!f) return 6;
+        printf("c%u", eta); for (int i = 0; i < 256; i++) printf(" %d", f[i].t); printf("\n");
+        free(f);
+    }
+    if (SamplePolyCBD(B, 4) != NULL) return 7;     /* unsupported eta: message + ml_errno, NULL */
+    printf("Test Complete!\n");
+    return 0;
+}
+"""
+
+
+def test_reference_primitive_symbols_through_the_shim(pkg, tmp_path, golden, golden_npz, oracle):
+    """the reference's objects also export SampleNTT / SamplePolyCBD / NTT / InverseNTT (4-byte `union
+    integer` cells) and its own test programs call them.  Same recipes, against the goldens G1-G3."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "prim_test.c"
+    src.write_text(PRIM_TEST_C)
+    exe = tmp_path / "prim_test"
+    libdir = os.path.dirname(pkg.SHIM_PATH)
+    subprocess.run(["gcc", "-O1", "-I", os.path.join(root, "include"), str(src), "-o", str(exe), "-L", libdir, "-lml_kem",
+                    "-lmlkem_amd", f"-Wl,-rpath,{libdir}"], check=True)
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
+    rows = {ln.split()[0]: np.array(ln.split()[1:], dtype=np.int64) for ln in r.stdout.splitlines() if ln and ln[0] in "fsc"}
+    assert rows["f1"].tolist() == [2931, 2112, 3266, 1044, 1856, 3090, 520, 2900]     # SURVEY 8c G1
+    assert rows["fh"].tolist() == [192, 1622, 2207, 476, 2400, 883, 637, 686]
+    for it in range(7):
+        seed = np.array([(it * i + i) & 0xFF for i in range(34)], np.uint8)
+        assert (rows[f"s{it}"] == oracle.sample_ntt(seed)).all(), it
+    assert (rows["s1"][:8] == rows["f1"]).all()                                         # it = 1 is G1's f1
+    b = np.arange(192, dtype=np.uint8)
+    assert rows["c3"][:8].tolist() == [0, 1, 3328, 0, 2, 3328, 3328, 1]                # SURVEY 8c G3
+    assert (rows["c3"] == oracle.sample_cbd(b[:192], 3)).all() and (rows["c2"] == oracle.sample_cbd(b[:128], 2)).all()
+    assert "eta must be 2 or 3" in r.stderr and "Test Complete!" in r.stdout
+
+
 @pytest.mark.parametrize("env", ({"MLKEM_OVERLAP": "1"}, {"MLKEM_RING": "128"}, {"MLKEM_RING": "32"}, {"MLKEM_HCHUNK_ITEMS": "300"}))
 def test_engine_options_do_not_change_results(pkg, torch, oracle, env, monkeypatch):
     """Opt-in execution modes read at context creation: two-stream sampler/arithmetic overlap, the 128-coefficient
