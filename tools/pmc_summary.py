@@ -37,7 +37,15 @@ for k in sorted(agg):
     if "FETCH_SIZE" in pd or "WRITE_SIZE" in pd:
         row["hbm_bytes_per_dispatch"] = {"read_raw": pd.get("FETCH_SIZE", 0) * 1024, "read_x2": pd.get("FETCH_SIZE", 0) * 2048,
                                          "write": pd.get("WRITE_SIZE", 0) * 1024}
+    if "SQ_INSTS_VALU" in pd and "GRBM_GUI_ACTIVE" in pd and pd["GRBM_GUI_ACTIVE"] > 0:
+        # GRBM_GUI_ACTIVE is summed over the 8 XCDs; 1024 SIMDs in all
+        simd_cycles = pd["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0
+        row["valu_instr_per_simd_cycle"] = pd["SQ_INSTS_VALU"] / simd_cycles
+        row["cycles_per_valu_instr"] = simd_cycles / pd["SQ_INSTS_VALU"]
+        if "SQ_WAVE_CYCLES" in pd:
+            row["resident_waves_per_simd"] = pd["SQ_WAVE_CYCLES"] * 4.0 / simd_cycles   # SQ_WAVE_CYCLES counts quad-cycles
     res[k] = row
-    print(k, "dispatches=%d" % n, " ".join("%s=%.4g" % (c, v) for c, v in sorted(pd.items())))
+    print(k, "dispatches=%d" % n, " ".join("%s=%.4g" % (c, v) for c, v in sorted(pd.items())),
+          " ".join("%s=%.3g" % (c, row[c]) for c in ("valu_instr_per_simd_cycle", "cycles_per_valu_instr", "resident_waves_per_simd") if c in row))
 if out_json:
     json.dump(res, open(out_json, "w"), indent=1)
