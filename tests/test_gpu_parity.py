@@ -108,7 +108,7 @@ def test_prf_and_hashes_vs_oracle_and_golden(engines, torch, golden, oracle):
         assert bytes(host(e.G(msgs))[1]).hex() == h["G"]
         assert bytes(host(e.J(msgs))[0]).hex() == h["J"]
     rng = np.random.default_rng(13)
-    for ln in (7, 136, 137, 168, 800, 1184, 1600):
+    for ln in (4, 7, 12, 100, 132, 136, 137, 140, 168, 172, 800, 1120, 1184, 1600):   # % 4 == 0 and full waves: LDS-DMA staging
         m = rng.integers(0, 256, (130, ln)).astype(np.uint8)
         H, G, J = host(e.H(dev(torch, m))), host(e.G(dev(torch, m))), host(e.J(dev(torch, m)))
         for i in (0, 63, 64, 129):
