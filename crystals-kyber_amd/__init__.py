@@ -27,6 +27,7 @@ ABI_SYMBOLS = (
     "mlkem_sizes", "mlkem_params", "mlkem_device_count", "mlkem_strerror", "mlkem_last_hip_error",
     "mlkem_ctx_create", "mlkem_ctx_destroy", "mlkem_ctx_scratch_bytes", "mlkem_timing_begin", "mlkem_timing_end",
     "mlkem_keygen_dev", "mlkem_encaps_dev", "mlkem_decaps_dev", "mlkem_encaps_status_dev", "mlkem_ctx_set_conformance",
+    "mlkem_pke_keygen_dev", "mlkem_pke_encrypt_dev", "mlkem_pke_decrypt_dev",
     "mlkem_ntt_dev", "mlkem_intt_dev", "mlkem_multiply_ntts_dev", "mlkem_sample_ntt_dev", "mlkem_sample_cbd_dev",
     "mlkem_prf_dev", "mlkem_hash_dev", "mlkem_keccak_sponge_dev", "mlkem_sha3_pad_bits",
     "mlkem_keygen", "mlkem_encaps", "mlkem_decaps", "mlkem_ntt", "mlkem_intt", "mlkem_keccak_sponge",
@@ -73,6 +74,9 @@ def load_library():
     L.mlkem_decaps_dev.argtypes = [vp, i32, sz, vp, vp, vp, vp, vp]
     L.mlkem_encaps_status_dev.argtypes = [vp, i32, sz, vp, vp, vp, vp, vp, vp]
     L.mlkem_ctx_set_conformance.argtypes = [vp, i32]
+    L.mlkem_pke_keygen_dev.argtypes = [vp, i32, sz, vp, vp, vp, vp]
+    L.mlkem_pke_encrypt_dev.argtypes = [vp, i32, sz, vp, vp, vp, vp, vp]
+    L.mlkem_pke_decrypt_dev.argtypes = [vp, i32, sz, vp, vp, vp, vp]
     L.mlkem_ntt_dev.argtypes = [vp, sz, vp, vp, vp]
     L.mlkem_intt_dev.argtypes = [vp, sz, vp, vp, vp]
     L.mlkem_multiply_ntts_dev.argtypes = [vp, sz, vp, vp, vp, vp]
@@ -139,6 +143,7 @@ class MLKEM:
         self.torch = torch
         self.lib = load_library()
         self.ek_len, self.dk_len, self.c_len = sizes(param_set)
+        self.k = (self.ek_len - 32) // 384
         self.param_set = param_set
         if not torch.cuda.is_available():
             raise MLKEMError(-100, "no HIP device visible (the engine has no CPU fallback)")
@@ -243,6 +248,38 @@ class MLKEM:
 
     def Decaps_internal(self, dk, c):
         return self.decaps(dk, c, hash_check=False)[0]
+
+    # -- K-PKE on its own ---------------------------------------------------
+    def PKE_KeyGen(self, d):
+        """K-PKE.KeyGen (ml_kem.c:651): d [n,32] -> ek [n,ek_len], dk_pke [n,384k]."""
+        d = self._dev(d, self.torch.uint8, 32)
+        n = d.shape[0]
+        ek, dk = self._out(n, self.ek_len), self._out(n, 384 * self.k)
+        self._check(self.lib.mlkem_pke_keygen_dev(self._ctx, self.param_set, n, d.data_ptr(), ek.data_ptr(), dk.data_ptr(), self._stream()))
+        return ek, dk
+
+    def PKE_Encrypt(self, ek, m, r):
+        """K-PKE.Encrypt (ml_kem.c:776): ek [n,ek_len], m, r [n,32] -> c [n,c_len]."""
+        u8 = self.torch.uint8
+        ek, m, r = self._dev(ek, u8, self.ek_len), self._dev(m, u8, 32), self._dev(r, u8, 32)
+        n = m.shape[0]
+        if ek.shape[0] != n or r.shape[0] != n:
+            raise MLKEMError(-101, "ek, m and r batch sizes differ")
+        c = self._out(n, self.c_len)
+        self._check(self.lib.mlkem_pke_encrypt_dev(self._ctx, self.param_set, n, ek.data_ptr(), m.data_ptr(), r.data_ptr(),
+                                                   c.data_ptr(), self._stream()))
+        return c
+
+    def PKE_Decrypt(self, dk_pke, c):
+        """K-PKE.Decrypt (ml_kem.c:942): dk_pke [n,384k], c [n,c_len] -> m [n,32]."""
+        u8 = self.torch.uint8
+        dk, c = self._dev(dk_pke, u8, 384 * self.k), self._dev(c, u8, self.c_len)
+        n = c.shape[0]
+        if dk.shape[0] != n:
+            raise MLKEMError(-101, "dk_pke and c batch sizes differ")
+        m = self._out(n, 32)
+        self._check(self.lib.mlkem_pke_decrypt_dev(self._ctx, self.param_set, n, dk.data_ptr(), c.data_ptr(), m.data_ptr(), self._stream()))
+        return m
 
     # -- batched primitives --------------------------------------------------------------------------
     def _poly(self, f):

@@ -299,7 +299,9 @@ k_decrypt(size_t n, const uint8_t* __restrict__ dk, size_t dk_stride, const uint
 // k_keygen — K-PKE.KeyGen after G and sampling (ml_kem.c:696-756) + the plain copies of KeyGen_internal
 // (ml_kem.c:1054-1062): ek = Enc12(t-hat) || rho ; dk = Enc12(s-hat) || ek || [H(ek)] || [z]
 // ------------------------------------------------------------------------------------------------
-template <int K, int ETA1>
+// KEM_DK = true : dk rows are the ML-KEM decapsulation keys (768k+96 bytes: ŝ ‖ ek ‖ H(ek) ‖ z; this kernel fills ŝ ‖ ek)
+// KEM_DK = false: K-PKE.KeyGen on its own (ml_kem.c:651-769): dk rows are the 384k bytes of ŝ only
+template <int K, int ETA1, bool KEM_DK>
 __global__ void __launch_bounds__(WAVE * ARITH_WAVES, MLKEM_ARITH_MINWAVES)
 k_keygen(size_t n, const uint16_t* __restrict__ A, const uint8_t* __restrict__ prf, const uint8_t* __restrict__ rho,
          uint8_t* __restrict__ ek, uint8_t* __restrict__ dk) {
@@ -308,7 +310,7 @@ k_keygen(size_t n, const uint16_t* __restrict__ A, const uint8_t* __restrict__ p
     const size_t item = (size_t)blockIdx.x * ARITH_WAVES + wv;
     if (item >= n) return;
     ArithLds<K>& L = lds_all[wv];
-    constexpr unsigned PS = (ETA1 == 3) ? 192 : 128, EK = 384 * K + 32, DK = 768 * K + 96;
+    constexpr unsigned PS = (ETA1 == 3) ? 192 : 128, EK = 384 * K + 32, DK = KEM_DK ? 768 * K + 96 : 384 * K;
     const uint8_t* my_prf = prf + item * (size_t)(2 * K * PS);
     const uint16_t* my_A = A + item * (size_t)(K * K * 256);
     uint8_t* my_ek = ek + item * EK;
@@ -358,11 +360,11 @@ k_keygen(size_t n, const uint16_t* __restrict__ A, const uint8_t* __restrict__ p
         wave_ntt_f(e, L.xch, tw);
 #pragma unroll
         for (int m = 0; m < 4; m++) acc[m] += e[m];   // <= 1665 + 6660
-        emit_encode12(L.cbuf, acc, my_ek + 384 * a, my_dk + 384 * K + 384 * a);
+        emit_encode12(L.cbuf, acc, my_ek + 384 * a, KEM_DK ? my_dk + 384 * K + 384 * a : (uint8_t*)nullptr);
     }
     if (l < 8) {
         reinterpret_cast<uint32_t*>(my_ek + 384 * K)[l] = rho_w;
-        reinterpret_cast<uint32_t*>(my_dk + 768 * K)[l] = rho_w;
+        if (KEM_DK) reinterpret_cast<uint32_t*>(my_dk + 768 * K)[l] = rho_w;
     }
 }
 

@@ -219,6 +219,37 @@ int mlkem_keygen_dev(mlkem_ctx* ctx, int set, size_t n, const uint8_t* d, const 
     return MLKEM_OK;
 }
 
+// ---- K-PKE on its own (ml_kem.c:651 / :776 / :942; static in the reference, reachable there through KeyGen_internal /
+// Encaps_internal / Decaps_internal and through the oracle's harness) ------------------------------------------------
+int mlkem_pke_keygen_dev(mlkem_ctx* ctx, int set, size_t n, const uint8_t* d, uint8_t* ek, uint8_t* dk_pke, void* stream) {
+    ParamSet p;
+    if (!param_set(set, p)) return MLKEM_ERR_PARAM_SET;
+    if (!ctx || (n && (!d || !ek || !dk_pke))) return MLKEM_ERR_ARG;
+    if (!aligned16(d) || !aligned16(ek) || !aligned16(dk_pke)) return MLKEM_ERR_ARG;
+    if (n) pke_keygen_dispatch(static_cast<hipStream_t>(stream), set, n, d, ek, dk_pke, ctx->ws);
+    HIP_TRY(hipGetLastError());
+    return MLKEM_OK;
+}
+int mlkem_pke_encrypt_dev(mlkem_ctx* ctx, int set, size_t n, const uint8_t* ek, const uint8_t* m, const uint8_t* r, uint8_t* c,
+                          void* stream) {
+    ParamSet p;
+    if (!param_set(set, p)) return MLKEM_ERR_PARAM_SET;
+    if (!ctx || (n && (!ek || !m || !r || !c))) return MLKEM_ERR_ARG;
+    if (!aligned16(ek) || !aligned16(m) || !aligned16(r) || !aligned16(c)) return MLKEM_ERR_ARG;
+    if (n) pke_encrypt_dispatch(static_cast<hipStream_t>(stream), set, n, ek, m, r, c, ctx->ws);
+    HIP_TRY(hipGetLastError());
+    return MLKEM_OK;
+}
+int mlkem_pke_decrypt_dev(mlkem_ctx* ctx, int set, size_t n, const uint8_t* dk_pke, const uint8_t* c, uint8_t* m, void* stream) {
+    ParamSet p;
+    if (!param_set(set, p)) return MLKEM_ERR_PARAM_SET;
+    if (!ctx || (n && (!dk_pke || !c || !m))) return MLKEM_ERR_ARG;
+    if (!aligned16(dk_pke) || !aligned16(c) || !aligned16(m)) return MLKEM_ERR_ARG;
+    pke_decrypt_dispatch(static_cast<hipStream_t>(stream), set, n, dk_pke, c, m);
+    HIP_TRY(hipGetLastError());
+    return MLKEM_OK;
+}
+
 int mlkem_encaps_status_dev(mlkem_ctx* ctx, int set, size_t n, const uint8_t* ek, const uint8_t* m, uint8_t* c, uint8_t* K,
                             int32_t* status, void* stream) {
     ParamSet p;

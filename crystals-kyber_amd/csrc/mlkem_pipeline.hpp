@@ -186,10 +186,12 @@ inline void launch_sample(stream_t st, const ParamSet& p, size_t n, const uint8_
     launch("k_sample_tail", k_sample, (size_t)t.xof_blocks, WAVE, st, t);
 }
 
-// ---- ML-KEM.KeyGen_internal (ml_kem.c:1034-1084) -------------------------------------------------
+// ---- ML-KEM.KeyGen_internal (ml_kem.c:1034-1084) ; z == nullptr: K-PKE.KeyGen alone (ml_kem.c:651-769, dk = 384k-byte ŝ) ----
 template <int K, int ETA1>
 inline void keygen_run(stream_t st, const ParamSet& p, size_t n, const uint8_t* d, const uint8_t* z, uint8_t* ek, uint8_t* dk,
                        const Workspace& ws) {
+    const bool kem = z != nullptr;
+    const size_t dk_len = kem ? (size_t)p.dk_len : (size_t)(384 * K);
     for (size_t h0 = 0; h0 < n; h0 += ws.hcap) {
         const size_t hn = min_sz(ws.hcap, n - h0);
         launch("k_hash_keygen_seed", k_hash_keygen_seed<K>, ceil_div(hn, WAVE), WAVE, st, hn, d + h0 * 32, ws.rho, ws.r);
@@ -199,31 +201,40 @@ inline void keygen_run(stream_t st, const ParamSet& p, size_t n, const uint8_t* 
             const int buf = pipe.begin_chunk();
             const Workspace w = ws.view(buf);
             launch_sample(st, p, cn, ws.rho + c0 * 32, 32, /*transpose=*/0, ws.r + c0 * 32, 2 * K, 2 * K, w);
-            launch("k_keygen", k_keygen<K, ETA1>, ceil_div(cn, ARITH_WAVES), WAVE * ARITH_WAVES, pipe.arith_stream(buf), cn,
-                   (const uint16_t*)w.A, (const uint8_t*)w.prf, (const uint8_t*)(ws.rho + c0 * 32), ek + i0 * p.ek_len,
-                   dk + i0 * p.dk_len);
+            if (kem)
+                launch("k_keygen", k_keygen<K, ETA1, true>, ceil_div(cn, ARITH_WAVES), WAVE * ARITH_WAVES, pipe.arith_stream(buf), cn,
+                       (const uint16_t*)w.A, (const uint8_t*)w.prf, (const uint8_t*)(ws.rho + c0 * 32), ek + i0 * p.ek_len,
+                       dk + i0 * dk_len);
+            else
+                launch("k_keygen", k_keygen<K, ETA1, false>, ceil_div(cn, ARITH_WAVES), WAVE * ARITH_WAVES, pipe.arith_stream(buf), cn,
+                       (const uint16_t*)w.A, (const uint8_t*)w.prf, (const uint8_t*)(ws.rho + c0 * 32), ek + i0 * p.ek_len,
+                       dk + i0 * dk_len);
             pipe.end_chunk(buf);
         }
         pipe.join();
-        launch("k_hash_keygen_fin", k_hash_keygen_fin<K>, ceil_div(hn, WAVE), WAVE, st, hn, (const uint8_t*)(ek + h0 * p.ek_len),
-               z + h0 * 32, dk + h0 * p.dk_len);
+        if (kem)
+            launch("k_hash_keygen_fin", k_hash_keygen_fin<K>, ceil_div(hn, WAVE), WAVE, st, hn, (const uint8_t*)(ek + h0 * p.ek_len),
+                   z + h0 * 32, dk + h0 * p.dk_len);
     }
 }
 
 // ---- ML-KEM.Encaps_internal (ml_kem.c:1093-1130) -------------------------------------------------
 template <int K, int ETA1, int DU, int DV>
+// r_user != nullptr: K-PKE.Encrypt alone (ml_kem.c:776-936) with the caller's randomness; no hashing, Kout unused
 inline void encaps_run(stream_t st, const ParamSet& p, size_t n, const uint8_t* ek, const uint8_t* m, uint8_t* c, uint8_t* Kout,
-                       int32_t* mod_status, const Workspace& ws) {
+                       int32_t* mod_status, const Workspace& ws, const uint8_t* r_user = nullptr) {
     for (size_t h0 = 0; h0 < n; h0 += ws.hcap) {
         const size_t hn = min_sz(ws.hcap, n - h0);
-        launch("k_hash_encaps", k_hash_encaps<K>, ceil_div(hn, WAVE), WAVE, st, hn, ek + h0 * p.ek_len, m + h0 * 32, Kout + h0 * 32, ws.r);
+        const uint8_t* r_h = r_user ? r_user + h0 * 32 : (const uint8_t*)ws.r;
+        if (!r_user)
+            launch("k_hash_encaps", k_hash_encaps<K>, ceil_div(hn, WAVE), WAVE, st, hn, ek + h0 * p.ek_len, m + h0 * 32, Kout + h0 * 32, ws.r);
         ChunkPipe pipe(ws, st, ceil_div(hn, ws.cap));
         for (size_t c0 = 0; c0 < hn; c0 += ws.cap) {
             const size_t cn = min_sz(ws.cap, hn - c0), i0 = h0 + c0;
             const uint8_t* eki = ek + i0 * p.ek_len;
             const int buf = pipe.begin_chunk();
             const Workspace w = ws.view(buf);
-            launch_sample(st, p, cn, eki + 384 * K, p.ek_len, /*transpose=*/1, ws.r + c0 * 32, 2 * K + 1, K, w);
+            launch_sample(st, p, cn, eki + 384 * K, p.ek_len, /*transpose=*/1, r_h + c0 * 32, 2 * K + 1, K, w);
             launch("k_encrypt", k_encrypt<K, ETA1, DU, DV, false>, ceil_div(cn, ARITH_WAVES), WAVE * ARITH_WAVES,
                    pipe.arith_stream(buf), cn, eki, (size_t)p.ek_len, m + i0 * 32, (const uint16_t*)w.A, (const uint8_t*)w.prf,
                    c + i0 * p.c_len, (const uint8_t*)nullptr, (const uint8_t*)nullptr, (const uint8_t*)nullptr, (uint8_t*)nullptr,
@@ -292,6 +303,33 @@ inline int encaps_dispatch(stream_t st, int set, size_t n, const uint8_t* ek, co
     case 512: encaps_run<2, 3, 10, 4>(st, p, n, ek, m, c, K, mod_status, ws); break;
     case 768: encaps_run<3, 2, 10, 4>(st, p, n, ek, m, c, K, mod_status, ws); break;
     default: encaps_run<4, 2, 11, 5>(st, p, n, ek, m, c, K, mod_status, ws); break;
+    }
+    return 0;
+}
+// K-PKE on its own: PKE_KeyGen / PKE_Encrypt / PKE_Decrypt
+inline int pke_keygen_dispatch(stream_t st, int set, size_t n, const uint8_t* d, uint8_t* ek, uint8_t* dk_pke, const Workspace& ws) {
+    return keygen_dispatch(st, set, n, d, nullptr, ek, dk_pke, ws);
+}
+inline int pke_encrypt_dispatch(stream_t st, int set, size_t n, const uint8_t* ek, const uint8_t* m, const uint8_t* r, uint8_t* c,
+                                const Workspace& ws) {
+    ParamSet p;
+    if (!param_set(set, p) || !r) return -1;
+    switch (set) {
+    case 512: encaps_run<2, 3, 10, 4>(st, p, n, ek, m, c, nullptr, nullptr, ws, r); break;
+    case 768: encaps_run<3, 2, 10, 4>(st, p, n, ek, m, c, nullptr, nullptr, ws, r); break;
+    default: encaps_run<4, 2, 11, 5>(st, p, n, ek, m, c, nullptr, nullptr, ws, r); break;
+    }
+    return 0;
+}
+inline int pke_decrypt_dispatch(stream_t st, int set, size_t n, const uint8_t* dk_pke, const uint8_t* c, uint8_t* m) {
+    ParamSet p;
+    if (!param_set(set, p)) return -1;
+    const size_t grid = ceil_div(n, ARITH_WAVES);
+    if (n == 0) return 0;
+    switch (set) {
+    case 512: launch("k_decrypt", k_decrypt<2, 10, 4>, grid, WAVE * ARITH_WAVES, st, n, dk_pke, (size_t)(384 * 2), c, m); break;
+    case 768: launch("k_decrypt", k_decrypt<3, 10, 4>, grid, WAVE * ARITH_WAVES, st, n, dk_pke, (size_t)(384 * 3), c, m); break;
+    default: launch("k_decrypt", k_decrypt<4, 11, 5>, grid, WAVE * ARITH_WAVES, st, n, dk_pke, (size_t)(384 * 4), c, m); break;
     }
     return 0;
 }

@@ -96,6 +96,17 @@ int mlkem_encaps_status_dev(mlkem_ctx* ctx, int param_set, size_t n, const uint8
 int mlkem_decaps_dev(mlkem_ctx* ctx, int param_set, size_t n, const uint8_t* dk, const uint8_t* c, uint8_t* K, int32_t* status,
                      void* stream);
 
+/* ---- K-PKE on its own, device pointers -----------------------------------------------------
+ * replaces PKE_KeyGen(params, d)          ml_kem.c:651-769  d : n x 32  ->  ek : n x (384k+32), dk_pke : n x 384k
+ * replaces PKE_Encrypt(params, ek, m, r)  ml_kem.c:776-936  m, r : n x 32  ->  c : n x 32(du k + dv)
+ * replaces PKE_Decrypt(params, dk, c)     ml_kem.c:942-1023 dk_pke : n x 384k  ->  m : n x 32
+ * (static in the reference: reached there through KeyGen_internal / Encaps_internal / Decaps_internal) */
+int mlkem_pke_keygen_dev(mlkem_ctx* ctx, int param_set, size_t n, const uint8_t* d, uint8_t* ek, uint8_t* dk_pke, void* stream);
+int mlkem_pke_encrypt_dev(mlkem_ctx* ctx, int param_set, size_t n, const uint8_t* ek, const uint8_t* m, const uint8_t* r,
+                          uint8_t* c, void* stream);
+int mlkem_pke_decrypt_dev(mlkem_ctx* ctx, int param_set, size_t n, const uint8_t* dk_pke, const uint8_t* c, uint8_t* m,
+                          void* stream);
+
 /* ---- batched primitives, device pointers (BASELINE config 2 and component parity tests) ------------ */
 /* replaces NTT(f)              ml_kem.c:287-329 ; in/out : n x uint16[256], coefficients in [0, q) */
 int mlkem_ntt_dev(mlkem_ctx* ctx, size_t n, const uint16_t* f, uint16_t* f_hat, void* stream);

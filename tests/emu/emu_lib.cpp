@@ -60,6 +60,21 @@ int emu_decaps(int set, size_t n, const uint8_t* dk, const uint8_t* c, uint8_t* 
     free_ws(ws);
     return rc;
 }
+int emu_pke_keygen(int set, size_t n, const uint8_t* d, uint8_t* ek, uint8_t* dk_pke) {
+    Workspace ws = make_ws(n);
+    int rc = pke_keygen_dispatch(nullptr, set, n, d, ek, dk_pke, ws);
+    free_ws(ws);
+    return rc;
+}
+int emu_pke_encrypt(int set, size_t n, const uint8_t* ek, const uint8_t* m, const uint8_t* r, uint8_t* c) {
+    Workspace ws = make_ws(n);
+    int rc = pke_encrypt_dispatch(nullptr, set, n, ek, m, r, c, ws);
+    free_ws(ws);
+    return rc;
+}
+int emu_pke_decrypt(int set, size_t n, const uint8_t* dk_pke, const uint8_t* c, uint8_t* m) {
+    return pke_decrypt_dispatch(nullptr, set, n, dk_pke, c, m);
+}
 void emu_ntt(int inverse, size_t n, const uint16_t* in, uint16_t* out) { ntt_launch(nullptr, inverse != 0, n, in, out); }
 void emu_basemul(size_t n, const uint16_t* a, const uint16_t* b, uint16_t* h) { basemul_launch(nullptr, n, a, b, h); }
 int emu_cbd(int eta, size_t n, const uint8_t* bytes, uint16_t* out) { return cbd_launch(nullptr, eta, n, bytes, out); }

@@ -110,6 +110,27 @@ def test_emu_kem_matches_oracle_and_golden(emu, oracle, golden, pset):
 
 
 @pytest.mark.parametrize("pset", (512, 768, 1024))
+def test_emu_k_pke_alone(emu, oracle, pset):
+    """PKE_KeyGen / PKE_Encrypt (caller's randomness) / PKE_Decrypt as stand-alone entry points."""
+    ekl, dkl, cl = SIZES[pset]
+    k = {512: 2, 768: 3, 1024: 4}[pset]
+    n = 6
+    d, m, r = seeds("pke-d", n, pset), seeds("pke-m", n, pset), seeds("pke-r", n, pset)
+    ek, dkp = np.zeros((n, ekl), np.uint8), np.zeros((n, 384 * k), np.uint8)
+    assert emu.emu_pke_keygen(pset, C.c_size_t(n), p8(d), p8(ek), p8(dkp)) == 0
+    c = np.zeros((n, cl), np.uint8)
+    assert emu.emu_pke_encrypt(pset, C.c_size_t(n), p8(ek), p8(m), p8(r), p8(c)) == 0
+    m2 = np.zeros((n, 32), np.uint8)
+    assert emu.emu_pke_decrypt(pset, C.c_size_t(n), p8(dkp), p8(c), p8(m2)) == 0
+    for i in range(n):
+        ek_o, dk_o = oracle.pke_keygen(pset, d[i])
+        assert (ek[i] == ek_o).all() and (dkp[i] == dk_o).all()
+        assert (c[i] == oracle.pke_encrypt(pset, ek_o, m[i], r[i])).all()
+        assert (m2[i] == oracle.pke_decrypt(pset, dk_o, c[i])).all()
+    assert (m2 == m).all()
+
+
+@pytest.mark.parametrize("pset", (512, 768, 1024))
 def test_emu_full_wave_hash_kernels_take_the_dma_staging(emu, oracle, pset):
     """64 + 3 items: the first wave of k_hash_encaps / k_hash_decaps / k_hash_keygen_fin is complete, so its sponges are
     fed by the LDS-DMA staging (one- and two-segment messages, partial last column at ML-KEM-512: 800 = 5*136 + 120);

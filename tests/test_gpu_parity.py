@@ -198,6 +198,28 @@ def test_kem_vs_oracle_ragged_batches(engines, torch, oracle, pset, n):
     assert (host(st) == st_o).all() and (host(Kd) == Kd_o).all()
 
 
+@pytest.mark.parametrize("pset", SETS)
+def test_k_pke_alone_vs_oracle(engines, torch, oracle, pset):
+    """SURVEY 8a rows a21-a23 as stand-alone entry points (PKE_KeyGen / PKE_Encrypt with the caller's randomness /
+    PKE_Decrypt); 150 items = two full waves + a ragged one for the lane-per-item hash stage of PKE_KeyGen."""
+    e = engines[pset]
+    n = 150
+    d, m, r = seeds("pke-d", n, pset), seeds("pke-m", n, pset), seeds("pke-r", n, pset)
+    ek, dkp = e.PKE_KeyGen(dev(torch, d))
+    c = e.PKE_Encrypt(ek, dev(torch, m), dev(torch, r))
+    m2 = e.PKE_Decrypt(dkp, c)
+    ekh, dkh, ch = host(ek), host(dkp), host(c)
+    for i in (0, 1, 63, 64, 127, 128, 149):
+        ek_o, dk_o = oracle.pke_keygen(pset, d[i])
+        assert (ekh[i] == ek_o).all() and (dkh[i] == dk_o).all()
+        assert (ch[i] == oracle.pke_encrypt(pset, ek_o, m[i], r[i])).all()
+    assert (host(m2) == m).all()
+    # the KEM layers on top: dk = dk_pke || ek || H(ek) || z and c = Encrypt(ek, m, r) with (K, r) = G(m || H(ek))
+    z = seeds("pke-z", n, pset)
+    ek2, dk2 = e.keygen(dev(torch, d), dev(torch, z))
+    assert (host(ek2) == ekh).all() and (host(dk2)[:, : 384 * e.k] == dkh).all()
+
+
 def test_empty_batches(engines, torch):
     e = engines[768]
     u8 = torch.uint8
