@@ -29,6 +29,7 @@ ABI_SYMBOLS = (
     "mlkem_keygen_dev", "mlkem_encaps_dev", "mlkem_decaps_dev", "mlkem_encaps_status_dev", "mlkem_ctx_set_conformance",
     "mlkem_pke_keygen_dev", "mlkem_pke_encrypt_dev", "mlkem_pke_decrypt_dev",
     "mlkem_ntt_dev", "mlkem_intt_dev", "mlkem_multiply_ntts_dev", "mlkem_sample_ntt_dev", "mlkem_sample_cbd_dev",
+    "mlkem_compress_encode_dev", "mlkem_decode_decompress_dev",
     "mlkem_prf_dev", "mlkem_hash_dev", "mlkem_keccak_sponge_dev", "mlkem_sha3_pad_bits",
     "mlkem_keygen", "mlkem_encaps", "mlkem_decaps", "mlkem_ntt", "mlkem_intt", "mlkem_keccak_sponge",
     "mlkem_sample_ntt", "mlkem_sample_cbd",
@@ -83,6 +84,8 @@ def load_library():
     L.mlkem_sample_ntt_dev.argtypes = [vp, sz, vp, vp, vp]
     L.mlkem_sample_cbd_dev.argtypes = [vp, i32, sz, vp, vp, vp]
     L.mlkem_prf_dev.argtypes = [vp, i32, sz, vp, vp, vp]
+    L.mlkem_compress_encode_dev.argtypes = [vp, i32, sz, vp, vp, vp]
+    L.mlkem_decode_decompress_dev.argtypes = [vp, i32, sz, vp, vp, vp]
     L.mlkem_hash_dev.argtypes = [vp, i32, sz, vp, C.c_uint, sz, vp, vp]
     L.mlkem_keygen.argtypes = [i32, sz, vp, vp, vp, vp]
     L.mlkem_encaps.argtypes = [i32, sz, vp, vp, vp, vp]
@@ -324,6 +327,20 @@ class MLKEM:
         b = self._dev(data, self.torch.uint8, 64 * eta)
         out = self._out(b.shape[0], 256, self.torch.int16)
         self._check(self.lib.mlkem_sample_cbd_dev(self._ctx, eta, b.shape[0], b.data_ptr(), out.data_ptr(), self._stream()))
+        return out
+
+    def compress_encode(self, f, d):
+        """ByteEncode_d(Compress_d(f)) (ml_kem.c:83, :125) for d in {1,4,5,10,11}; d = 12: ByteEncode_12 of canonical f."""
+        f = self._poly(f)
+        out = self._out(f.shape[0], 32 * d)
+        self._check(self.lib.mlkem_compress_encode_dev(self._ctx, d, f.shape[0], f.data_ptr(), out.data_ptr(), self._stream()))
+        return out
+
+    def decode_decompress(self, data, d):
+        """Decompress_d(ByteDecode_d(B)) (ml_kem.c:153, :104); d = 12: raw 12-bit values (no reduction, F3)."""
+        b = self._dev(data, self.torch.uint8, 32 * d)
+        out = self._out(b.shape[0], 256, self.torch.int16)
+        self._check(self.lib.mlkem_decode_decompress_dev(self._ctx, d, b.shape[0], b.data_ptr(), out.data_ptr(), self._stream()))
         return out
 
     def prf(self, in33, eta):

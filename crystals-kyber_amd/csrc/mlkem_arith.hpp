@@ -444,6 +444,44 @@ __global__ void __launch_bounds__(WAVE * ARITH_WAVES) k_cbd_batch(size_t n, cons
     }
 }
 
+// Compress_D + ByteEncode_D (ml_kem.c:83-97, :125-145; D = 12: ByteEncode_12 alone) and ByteDecode_D + Decompress_D
+// (ml_kem.c:153-177, :104-119; D = 12: raw 12-bit values, no reduction -- F3) over n polynomials: the codec helpers the
+// K-PKE kernels use, as stand-alone primitives for component parity against the reference's full Compress tables.
+template <int D>
+__global__ void __launch_bounds__(WAVE * ARITH_WAVES) k_encode_batch(size_t n, const uint16_t* __restrict__ f, uint8_t* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) uint32_t cbuf_all[ARITH_WAVES][CODEC_BUF_WORDS];
+    const int wv = (int)(threadIdx.x >> 6);
+    uint32_t* cbuf = cbuf_all[wv];
+    const size_t stride = (size_t)gridDim.x * ARITH_WAVES;
+    for (size_t p = (size_t)blockIdx.x * ARITH_WAVES + wv; p < n; p += stride) {
+        float x[4];
+        load_poly_nat_f12(f + p * 256, x);
+        if constexpr (D == 12) {
+            emit_encode12(cbuf, x, out + p * 384, nullptr);
+        } else {
+            CodecRegs<D> unused{};
+            emit_compressed<D, false>(cbuf, x, out + p * (32 * D), unused);
+        }
+    }
+}
+template <int D>
+__global__ void __launch_bounds__(WAVE * ARITH_WAVES) k_decode_batch(size_t n, const uint8_t* __restrict__ in, uint16_t* __restrict__ f) {
+    __shared__ __attribute__((aligned(16))) uint32_t cbuf_all[ARITH_WAVES][CODEC_BUF_WORDS];
+    const int wv = (int)(threadIdx.x >> 6);
+    uint32_t* cbuf = cbuf_all[wv];
+    const size_t stride = (size_t)gridDim.x * ARITH_WAVES;
+    for (size_t p = (size_t)blockIdx.x * ARITH_WAVES + wv; p < n; p += stride) {
+        CodecRegs<D> r;
+        codec_fetch<D>(in + p * (32 * D), r);
+        float x[4];
+        decode_regs<D, D != 12>(cbuf, r, x);
+        int xi[4];
+#pragma unroll
+        for (int m = 0; m < 4; m++) xi[m] = (int)x[m];
+        store_poly_nat(f + p * 256, xi);
+    }
+}
+
 // ================================================================================================
 // layout converters: the reference keeps every "byte" in a 4-byte `union byte` cell (value in bits
 // 0-7, upper 24 bits undefined: ml_kem.h:35-38).  Pure streaming kernels, 16 cells (64 B in / 16 B out, or

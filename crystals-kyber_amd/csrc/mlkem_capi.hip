@@ -318,6 +318,20 @@ int mlkem_sample_cbd_dev(mlkem_ctx* ctx, int eta, size_t n, const uint8_t* bytes
     HIP_TRY(hipGetLastError());
     return MLKEM_OK;
 }
+int mlkem_compress_encode_dev(mlkem_ctx* ctx, int d, size_t n, const uint16_t* f, uint8_t* bytes, void* stream) {
+    if (!ctx || (n && (!f || !bytes)) || !aligned16(f) || (reinterpret_cast<uintptr_t>(bytes) & 3u)) return MLKEM_ERR_ARG;
+    if (d != 1 && d != 4 && d != 5 && d != 10 && d != 11 && d != 12) return MLKEM_ERR_ARG;
+    if (n) codec_launch(static_cast<hipStream_t>(stream), true, d, n, f, bytes);
+    HIP_TRY(hipGetLastError());
+    return MLKEM_OK;
+}
+int mlkem_decode_decompress_dev(mlkem_ctx* ctx, int d, size_t n, const uint8_t* bytes, uint16_t* f, void* stream) {
+    if (!ctx || (n && (!f || !bytes)) || !aligned16(f) || (reinterpret_cast<uintptr_t>(bytes) & 3u)) return MLKEM_ERR_ARG;
+    if (d != 1 && d != 4 && d != 5 && d != 10 && d != 11 && d != 12) return MLKEM_ERR_ARG;
+    if (n) codec_launch(static_cast<hipStream_t>(stream), false, d, n, bytes, f);
+    HIP_TRY(hipGetLastError());
+    return MLKEM_OK;
+}
 int mlkem_prf_dev(mlkem_ctx* ctx, int eta, size_t n, const uint8_t* in33, uint8_t* out, void* stream) {
     if (!ctx || (n && (!in33 || !out)) || !aligned16(out)) return MLKEM_ERR_ARG;
     if (n && prf_launch(static_cast<hipStream_t>(stream), eta, n, in33, out)) return MLKEM_ERR_ARG;

@@ -364,6 +364,19 @@ inline int cbd_launch(stream_t st, int eta, size_t n, const uint8_t* bytes, uint
     else return -1;
     return 0;
 }
+// Compress+ByteEncode / ByteDecode+Decompress for the d values ML-KEM uses
+inline int codec_launch(stream_t st, bool encode, int d, size_t n, const void* in, void* out) {
+#define MLKEM_CODEC_CASE(D)                                                                                                    \
+    case D:                                                                                                                    \
+        if (encode) launch("k_encode_batch", k_encode_batch<D>, poly_grid(n), WAVE * ARITH_WAVES, st, n, (const uint16_t*)in, (uint8_t*)out); \
+        else launch("k_decode_batch", k_decode_batch<D>, poly_grid(n), WAVE * ARITH_WAVES, st, n, (const uint8_t*)in, (uint16_t*)out);        \
+        return 0;
+    switch (d) {
+        MLKEM_CODEC_CASE(1) MLKEM_CODEC_CASE(4) MLKEM_CODEC_CASE(5) MLKEM_CODEC_CASE(10) MLKEM_CODEC_CASE(11) MLKEM_CODEC_CASE(12)
+    default: return -1;
+    }
+#undef MLKEM_CODEC_CASE
+}
 // stand-alone SampleNTT over explicit 34-byte seeds: the general kernel in direct mode
 inline void sample_ntt_launch(stream_t st, size_t n, const uint8_t* seeds34, uint16_t* out) {
     SampleArgs a{};

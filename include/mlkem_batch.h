@@ -114,6 +114,12 @@ int mlkem_ntt_dev(mlkem_ctx* ctx, size_t n, const uint16_t* f, uint16_t* f_hat, 
 int mlkem_intt_dev(mlkem_ctx* ctx, size_t n, const uint16_t* f_hat, uint16_t* f, void* stream);
 /* replaces MultiplyNTTs(f, g)  ml_kem.c:415-442 ; inputs may be any 12-bit value (as ByteDecode_12 yields) */
 int mlkem_multiply_ntts_dev(mlkem_ctx* ctx, size_t n, const uint16_t* f_hat, const uint16_t* g_hat, uint16_t* h_hat, void* stream);
+/* replaces ByteEncode(Compress(f, d), d)   ml_kem.c:83-97 + :125-145 ; f : n x uint16[256] -> bytes : n x 32d ;
+ *          d in {1, 4, 5, 10, 11} (coefficients taken mod 2^12, then mod q) ; d = 12 : ByteEncode_12 alone (ml_kem.c:736-756) */
+int mlkem_compress_encode_dev(mlkem_ctx* ctx, int d, size_t n, const uint16_t* f, uint8_t* bytes, void* stream);
+/* replaces Decompress(ByteDecode(B, d), d) ml_kem.c:153-177 + :104-119 ; d = 12 : the raw 12-bit values, NOT reduced mod q
+ *          (ml_kem.c:170) */
+int mlkem_decode_decompress_dev(mlkem_ctx* ctx, int d, size_t n, const uint8_t* bytes, uint16_t* f, void* stream);
 /* replaces SampleNTT(B)        ml_kem.c:189-245 ; seeds : n x 34 bytes (packed) */
 int mlkem_sample_ntt_dev(mlkem_ctx* ctx, size_t n, const uint8_t* seeds34, uint16_t* a_hat, void* stream);
 /* replaces SamplePolyCBD(B, eta) ml_kem.c:253-275 ; bytes : n x 64*eta */

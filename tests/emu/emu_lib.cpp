@@ -75,6 +75,7 @@ int emu_pke_encrypt(int set, size_t n, const uint8_t* ek, const uint8_t* m, cons
 int emu_pke_decrypt(int set, size_t n, const uint8_t* dk_pke, const uint8_t* c, uint8_t* m) {
     return pke_decrypt_dispatch(nullptr, set, n, dk_pke, c, m);
 }
+int emu_codec(int encode, int d, size_t n, const void* in, void* out) { return codec_launch(nullptr, encode != 0, d, n, in, out); }
 void emu_ntt(int inverse, size_t n, const uint16_t* in, uint16_t* out) { ntt_launch(nullptr, inverse != 0, n, in, out); }
 void emu_basemul(size_t n, const uint16_t* a, const uint16_t* b, uint16_t* h) { basemul_launch(nullptr, n, a, b, h); }
 int emu_cbd(int eta, size_t n, const uint8_t* bytes, uint16_t* out) { return cbd_launch(nullptr, eta, n, bytes, out); }

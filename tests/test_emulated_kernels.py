@@ -109,6 +109,37 @@ def test_emu_kem_matches_oracle_and_golden(emu, oracle, golden, pset):
     assert (Kd[1] == K[1]).all() and (Kd[4] == K[4]).all() and not (Kd[3] == K[3]).all()
 
 
+def _codec_cases(oracle, golden_npz, d):
+    """(polys in, bytes expected) for Compress+ByteEncode and (bytes in, polys expected) for ByteDecode+Decompress, from
+    the reference's full Compress / Decompress tables (G4) and its ByteEncode / ByteDecode (oracle = pinned restatement)."""
+    xs = np.zeros(14 * 256, np.uint16)
+    xs[:3329] = np.arange(3329)
+    xs = xs.reshape(14, 256)
+    if d == 12:
+        enc_want = np.stack([oracle.byte_encode(f, 12) for f in xs])
+        dec_in = golden_npz["g4_dec12_in"]                      # includes values >= q: stay unreduced (F3)
+        dec_want = golden_npz["g4_dec12_out"]
+    else:
+        comp, dec = golden_npz["g4_compress"][d - 1], golden_npz["g4_decompress"][d - 1]
+        enc_want = np.stack([oracle.byte_encode(comp[f], d) for f in xs])
+        ys = (np.arange(8 * 256) % (1 << d)).astype(np.uint16).reshape(8, 256)
+        dec_in = np.stack([oracle.byte_encode(y, d) for y in ys])
+        dec_want = dec[ys]
+    return xs, enc_want, np.ascontiguousarray(dec_in), dec_want
+
+
+@pytest.mark.parametrize("d", (1, 4, 5, 10, 11, 12))
+def test_emu_codec_primitives(emu, oracle, golden_npz, d):
+    xs, enc_want, dec_in, dec_want = _codec_cases(oracle, golden_npz, d)
+    out = np.zeros((xs.shape[0], 32 * d), np.uint8)
+    assert emu.emu_codec(1, d, C.c_size_t(xs.shape[0]), p16(xs), p8(out)) == 0
+    assert (out == enc_want).all()
+    f = np.zeros((dec_in.shape[0], 256), np.uint16)
+    assert emu.emu_codec(0, d, C.c_size_t(dec_in.shape[0]), p8(dec_in), p16(f)) == 0
+    assert (f == dec_want).all()
+    assert emu.emu_codec(1, 7, C.c_size_t(1), p16(xs), p8(out)) == -1
+
+
 @pytest.mark.parametrize("pset", (512, 768, 1024))
 def test_emu_k_pke_alone(emu, oracle, pset):
     """PKE_KeyGen / PKE_Encrypt (caller's randomness) / PKE_Decrypt as stand-alone entry points."""

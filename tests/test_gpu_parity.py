@@ -198,6 +198,19 @@ def test_kem_vs_oracle_ragged_batches(engines, torch, oracle, pset, n):
     assert (host(st) == st_o).all() and (host(Kd) == Kd_o).all()
 
 
+@pytest.mark.parametrize("d", (1, 4, 5, 10, 11, 12))
+def test_codec_primitives_vs_reference_tables(engines, torch, oracle, golden_npz, d):
+    """SURVEY 8a rows a4/a5 as stand-alone entry points: every x in [0, q) through Compress_d + ByteEncode_d and every
+    y in [0, 2^d) through ByteDecode_d + Decompress_d, against the reference's full tables (golden G4)."""
+    from test_emulated_kernels import _codec_cases
+    xs, enc_want, dec_in, dec_want = _codec_cases(oracle, golden_npz, d)
+    e = engines[768]
+    assert (host(e.compress_encode(dev(torch, xs.view(np.int16)), d)) == enc_want).all()
+    assert (as_u16(e.decode_decompress(dev(torch, dec_in), d)) == dec_want).all()
+    with pytest.raises(Exception):
+        e.compress_encode(dev(torch, xs.view(np.int16)), 7)
+
+
 @pytest.mark.parametrize("pset", SETS)
 def test_k_pke_alone_vs_oracle(engines, torch, oracle, pset):
     """SURVEY 8a rows a21-a23 as stand-alone entry points (PKE_KeyGen / PKE_Encrypt with the caller's randomness /
