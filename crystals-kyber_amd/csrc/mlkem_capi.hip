@@ -52,6 +52,13 @@ struct mlkem_ctx {
     Workspace ws;
 };
 
+// a context is bound to the device it was created on: its scratch lives there and `*_dev` calls launch on the CALLER's
+// current device, so a call made while another device is current is rejected instead of faulting on foreign memory
+static bool ctx_ok(const mlkem_ctx* ctx) {
+    int cur = -1;
+    return ctx && hipGetDevice(&cur) == hipSuccess && cur == ctx->device;
+}
+
 extern "C" {
 
 int mlkem_sizes(int set, unsigned* ek_len, unsigned* dk_len, unsigned* c_len) {
@@ -155,6 +162,8 @@ int mlkem_ctx_create(mlkem_ctx** out, int device, size_t chunk_items) {
 
 void mlkem_ctx_destroy(mlkem_ctx* ctx) {
     if (!ctx) return;
+    int prev = -1;
+    (void)hipGetDevice(&prev);
     (void)hipSetDevice(ctx->device);
     if (ctx->ws.helper) {
         (void)hipStreamSynchronize(ctx->ws.helper);
@@ -166,6 +175,7 @@ void mlkem_ctx_destroy(mlkem_ctx* ctx) {
     }
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     delete ctx;
+    if (prev >= 0) (void)hipSetDevice(prev);
 }
 
 size_t mlkem_ctx_scratch_bytes(const mlkem_ctx* ctx) { return ctx ? ctx->scratch_bytes : 0; }
@@ -211,7 +221,7 @@ int mlkem_timing_end(char* labels, double* total_ms, int* counts, int max) {
 int mlkem_keygen_dev(mlkem_ctx* ctx, int set, size_t n, const uint8_t* d, const uint8_t* z, uint8_t* ek, uint8_t* dk, void* stream) {
     ParamSet p;
     if (!param_set(set, p)) return MLKEM_ERR_PARAM_SET;
-    if (!ctx || (n && (!d || !z || !ek || !dk))) return MLKEM_ERR_ARG;
+    if (!ctx_ok(ctx) || (n && (!d || !z || !ek || !dk))) return MLKEM_ERR_ARG;
     if (!aligned16(d) || !aligned16(z) || !aligned16(ek) || !aligned16(dk)) return MLKEM_ERR_ARG;
     hipStream_t st = static_cast<hipStream_t>(stream);
     keygen_dispatch(st, set, n, d, z, ek, dk, ctx->ws);   // chunks internally through ctx->ws
@@ -224,7 +234,7 @@ int mlkem_keygen_dev(mlkem_ctx* ctx, int set, size_t n, const uint8_t* d, const 
 int mlkem_pke_keygen_dev(mlkem_ctx* ctx, int set, size_t n, const uint8_t* d, uint8_t* ek, uint8_t* dk_pke, void* stream) {
     ParamSet p;
     if (!param_set(set, p)) return MLKEM_ERR_PARAM_SET;
-    if (!ctx || (n && (!d || !ek || !dk_pke))) return MLKEM_ERR_ARG;
+    if (!ctx_ok(ctx) || (n && (!d || !ek || !dk_pke))) return MLKEM_ERR_ARG;
     if (!aligned16(d) || !aligned16(ek) || !aligned16(dk_pke)) return MLKEM_ERR_ARG;
     if (n) pke_keygen_dispatch(static_cast<hipStream_t>(stream), set, n, d, ek, dk_pke, ctx->ws);
     HIP_TRY(hipGetLastError());
@@ -234,7 +244,7 @@ int mlkem_pke_encrypt_dev(mlkem_ctx* ctx, int set, size_t n, const uint8_t* ek, 
                           void* stream) {
     ParamSet p;
     if (!param_set(set, p)) return MLKEM_ERR_PARAM_SET;
-    if (!ctx || (n && (!ek || !m || !r || !c))) return MLKEM_ERR_ARG;
+    if (!ctx_ok(ctx) || (n && (!ek || !m || !r || !c))) return MLKEM_ERR_ARG;
     if (!aligned16(ek) || !aligned16(m) || !aligned16(r) || !aligned16(c)) return MLKEM_ERR_ARG;
     if (n) pke_encrypt_dispatch(static_cast<hipStream_t>(stream), set, n, ek, m, r, c, ctx->ws);
     HIP_TRY(hipGetLastError());
@@ -243,7 +253,7 @@ int mlkem_pke_encrypt_dev(mlkem_ctx* ctx, int set, size_t n, const uint8_t* ek, 
 int mlkem_pke_decrypt_dev(mlkem_ctx* ctx, int set, size_t n, const uint8_t* dk_pke, const uint8_t* c, uint8_t* m, void* stream) {
     ParamSet p;
     if (!param_set(set, p)) return MLKEM_ERR_PARAM_SET;
-    if (!ctx || (n && (!dk_pke || !c || !m))) return MLKEM_ERR_ARG;
+    if (!ctx_ok(ctx) || (n && (!dk_pke || !c || !m))) return MLKEM_ERR_ARG;
     if (!aligned16(dk_pke) || !aligned16(c) || !aligned16(m)) return MLKEM_ERR_ARG;
     pke_decrypt_dispatch(static_cast<hipStream_t>(stream), set, n, dk_pke, c, m);
     HIP_TRY(hipGetLastError());
@@ -254,7 +264,7 @@ int mlkem_encaps_status_dev(mlkem_ctx* ctx, int set, size_t n, const uint8_t* ek
                             int32_t* status, void* stream) {
     ParamSet p;
     if (!param_set(set, p)) return MLKEM_ERR_PARAM_SET;
-    if (!ctx || (n && (!ek || !m || !c || !K))) return MLKEM_ERR_ARG;
+    if (!ctx_ok(ctx) || (n && (!ek || !m || !c || !K))) return MLKEM_ERR_ARG;
     if (!aligned16(ek) || !aligned16(m) || !aligned16(c) || !aligned16(K) || (reinterpret_cast<uintptr_t>(status) & 3u)) return MLKEM_ERR_ARG;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (status && !ctx->ws.fips) {   // reference mode: the reference's modulus check can never fail (ml_kem.c:1273-1291, F3)
@@ -270,7 +280,7 @@ int mlkem_encaps_dev(mlkem_ctx* ctx, int set, size_t n, const uint8_t* ek, const
 }
 
 int mlkem_ctx_set_conformance(mlkem_ctx* ctx, int mode) {
-    if (!ctx || (mode != MLKEM_CONFORMANCE_REFERENCE && mode != MLKEM_CONFORMANCE_FIPS203)) return MLKEM_ERR_ARG;
+    if (!ctx_ok(ctx) || (mode != MLKEM_CONFORMANCE_REFERENCE && mode != MLKEM_CONFORMANCE_FIPS203)) return MLKEM_ERR_ARG;
     ctx->ws.fips = mode == MLKEM_CONFORMANCE_FIPS203;
     return MLKEM_OK;
 }
@@ -278,7 +288,7 @@ int mlkem_ctx_set_conformance(mlkem_ctx* ctx, int mode) {
 int mlkem_decaps_dev(mlkem_ctx* ctx, int set, size_t n, const uint8_t* dk, const uint8_t* c, uint8_t* K, int32_t* status, void* stream) {
     ParamSet p;
     if (!param_set(set, p)) return MLKEM_ERR_PARAM_SET;
-    if (!ctx || (n && (!dk || !c || !K))) return MLKEM_ERR_ARG;
+    if (!ctx_ok(ctx) || (n && (!dk || !c || !K))) return MLKEM_ERR_ARG;
     if (!aligned16(dk) || !aligned16(c) || !aligned16(K) || (reinterpret_cast<uintptr_t>(status) & 3u)) return MLKEM_ERR_ARG;
     hipStream_t st = static_cast<hipStream_t>(stream);
     decaps_dispatch(st, set, n, dk, c, K, status, status != nullptr, ctx->ws);
@@ -289,77 +299,77 @@ int mlkem_decaps_dev(mlkem_ctx* ctx, int set, size_t n, const uint8_t* dk, const
 // ---- device-pointer primitives -------------------------------------------------------------------------
 
 int mlkem_ntt_dev(mlkem_ctx* ctx, size_t n, const uint16_t* f, uint16_t* fh, void* stream) {
-    if (!ctx || (n && (!f || !fh)) || !aligned16(f) || !aligned16(fh)) return MLKEM_ERR_ARG;
+    if (!ctx_ok(ctx) || (n && (!f || !fh)) || !aligned16(f) || !aligned16(fh)) return MLKEM_ERR_ARG;
     ntt_launch(static_cast<hipStream_t>(stream), false, n, f, fh);
     HIP_TRY(hipGetLastError());
     return MLKEM_OK;
 }
 int mlkem_intt_dev(mlkem_ctx* ctx, size_t n, const uint16_t* fh, uint16_t* f, void* stream) {
-    if (!ctx || (n && (!f || !fh)) || !aligned16(f) || !aligned16(fh)) return MLKEM_ERR_ARG;
+    if (!ctx_ok(ctx) || (n && (!f || !fh)) || !aligned16(f) || !aligned16(fh)) return MLKEM_ERR_ARG;
     ntt_launch(static_cast<hipStream_t>(stream), true, n, fh, f);
     HIP_TRY(hipGetLastError());
     return MLKEM_OK;
 }
 int mlkem_multiply_ntts_dev(mlkem_ctx* ctx, size_t n, const uint16_t* a, const uint16_t* b, uint16_t* h, void* stream) {
-    if (!ctx || (n && (!a || !b || !h)) || !aligned16(a) || !aligned16(b) || !aligned16(h)) return MLKEM_ERR_ARG;
+    if (!ctx_ok(ctx) || (n && (!a || !b || !h)) || !aligned16(a) || !aligned16(b) || !aligned16(h)) return MLKEM_ERR_ARG;
     basemul_launch(static_cast<hipStream_t>(stream), n, a, b, h);
     HIP_TRY(hipGetLastError());
     return MLKEM_OK;
 }
 int mlkem_sample_ntt_dev(mlkem_ctx* ctx, size_t n, const uint8_t* seeds34, uint16_t* a, void* stream) {
-    if (!ctx || (n && (!seeds34 || !a)) || !aligned16(a)) return MLKEM_ERR_ARG;
+    if (!ctx_ok(ctx) || (n && (!seeds34 || !a)) || !aligned16(a)) return MLKEM_ERR_ARG;
     if (n) sample_ntt_launch(static_cast<hipStream_t>(stream), n, seeds34, a);
     HIP_TRY(hipGetLastError());
     return MLKEM_OK;
 }
 int mlkem_sample_cbd_dev(mlkem_ctx* ctx, int eta, size_t n, const uint8_t* bytes, uint16_t* f, void* stream) {
-    if (!ctx || (n && (!bytes || !f)) || !aligned16(bytes) || !aligned16(f)) return MLKEM_ERR_ARG;
+    if (!ctx_ok(ctx) || (n && (!bytes || !f)) || !aligned16(bytes) || !aligned16(f)) return MLKEM_ERR_ARG;
     if (cbd_launch(static_cast<hipStream_t>(stream), eta, n, bytes, f)) return MLKEM_ERR_ARG;
     HIP_TRY(hipGetLastError());
     return MLKEM_OK;
 }
 int mlkem_compress_encode_dev(mlkem_ctx* ctx, int d, size_t n, const uint16_t* f, uint8_t* bytes, void* stream) {
-    if (!ctx || (n && (!f || !bytes)) || !aligned16(f) || (reinterpret_cast<uintptr_t>(bytes) & 3u)) return MLKEM_ERR_ARG;
+    if (!ctx_ok(ctx) || (n && (!f || !bytes)) || !aligned16(f) || (reinterpret_cast<uintptr_t>(bytes) & 3u)) return MLKEM_ERR_ARG;
     if (d != 1 && d != 4 && d != 5 && d != 10 && d != 11 && d != 12) return MLKEM_ERR_ARG;
     if (n) codec_launch(static_cast<hipStream_t>(stream), true, d, n, f, bytes);
     HIP_TRY(hipGetLastError());
     return MLKEM_OK;
 }
 int mlkem_decode_decompress_dev(mlkem_ctx* ctx, int d, size_t n, const uint8_t* bytes, uint16_t* f, void* stream) {
-    if (!ctx || (n && (!f || !bytes)) || !aligned16(f) || (reinterpret_cast<uintptr_t>(bytes) & 3u)) return MLKEM_ERR_ARG;
+    if (!ctx_ok(ctx) || (n && (!f || !bytes)) || !aligned16(f) || (reinterpret_cast<uintptr_t>(bytes) & 3u)) return MLKEM_ERR_ARG;
     if (d != 1 && d != 4 && d != 5 && d != 10 && d != 11 && d != 12) return MLKEM_ERR_ARG;
     if (n) codec_launch(static_cast<hipStream_t>(stream), false, d, n, bytes, f);
     HIP_TRY(hipGetLastError());
     return MLKEM_OK;
 }
 int mlkem_prf_dev(mlkem_ctx* ctx, int eta, size_t n, const uint8_t* in33, uint8_t* out, void* stream) {
-    if (!ctx || (n && (!in33 || !out)) || !aligned16(out)) return MLKEM_ERR_ARG;
+    if (!ctx_ok(ctx) || (n && (!in33 || !out)) || !aligned16(out)) return MLKEM_ERR_ARG;
     if (n && prf_launch(static_cast<hipStream_t>(stream), eta, n, in33, out)) return MLKEM_ERR_ARG;
     HIP_TRY(hipGetLastError());
     return MLKEM_OK;
 }
 int mlkem_hash_dev(mlkem_ctx* ctx, int kind, size_t n, const uint8_t* msg, unsigned len, size_t stride, uint8_t* out, void* stream) {
-    if (!ctx || (n && (!msg || !out)) || !aligned16(msg) || !aligned16(out)) return MLKEM_ERR_ARG;
+    if (!ctx_ok(ctx) || (n && (!msg || !out)) || !aligned16(msg) || !aligned16(out)) return MLKEM_ERR_ARG;
     if (n && hash_launch(static_cast<hipStream_t>(stream), kind, n, msg, len, stride, out)) return MLKEM_ERR_ARG;
     HIP_TRY(hipGetLastError());
     return MLKEM_OK;
 }
 int mlkem_keccak_sponge_dev(mlkem_ctx* ctx, unsigned rate, size_t n, const uint8_t* padded, unsigned nblocks, uint8_t* out,
                             unsigned outlen, size_t out_stride, void* stream) {
-    if (!ctx || (n && (!padded || !out)) || !aligned16(padded) || !aligned16(out)) return MLKEM_ERR_ARG;
+    if (!ctx_ok(ctx) || (n && (!padded || !out)) || !aligned16(padded) || !aligned16(out)) return MLKEM_ERR_ARG;
     if (n && sponge_raw_launch(static_cast<hipStream_t>(stream), rate, n, padded, nblocks, out, outlen, out_stride)) return MLKEM_ERR_ARG;
     HIP_TRY(hipGetLastError());
     return MLKEM_OK;
 }
 
 int mlkem_cells_to_bytes_dev(mlkem_ctx* ctx, size_t n, const uint32_t* cells, uint8_t* bytes, void* stream) {
-    if (!ctx || (n && (!cells || !bytes)) || !aligned16(cells) || !aligned16(bytes)) return MLKEM_ERR_ARG;
+    if (!ctx_ok(ctx) || (n && (!cells || !bytes)) || !aligned16(cells) || !aligned16(bytes)) return MLKEM_ERR_ARG;
     if (n) cells_launch(static_cast<hipStream_t>(stream), true, n, cells, bytes);
     HIP_TRY(hipGetLastError());
     return MLKEM_OK;
 }
 int mlkem_bytes_to_cells_dev(mlkem_ctx* ctx, size_t n, const uint8_t* bytes, uint32_t* cells, void* stream) {
-    if (!ctx || (n && (!cells || !bytes)) || !aligned16(cells) || !aligned16(bytes)) return MLKEM_ERR_ARG;
+    if (!ctx_ok(ctx) || (n && (!cells || !bytes)) || !aligned16(cells) || !aligned16(bytes)) return MLKEM_ERR_ARG;
     if (n) cells_launch(static_cast<hipStream_t>(stream), false, n, bytes, cells);
     HIP_TRY(hipGetLastError());
     return MLKEM_OK;

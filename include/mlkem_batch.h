@@ -56,7 +56,8 @@ const char* mlkem_last_hip_error(void);
 /* ---- engine context: owns the scratch HBM of one device --------------------------------------------- */
 typedef struct mlkem_ctx mlkem_ctx;
 /* `chunk_items` = items per sampler/arithmetic chunk (0 = default 2^18, env MLKEM_CHUNK_ITEMS); scratch is
- * ~10 KiB x chunk_items, allocated once here so that no *_dev call allocates. */
+ * ~10 KiB x chunk_items, allocated once here so that no *_dev call allocates.  A context is bound to `device`: *_dev
+ * calls launch on the caller's current HIP device and return MLKEM_ERR_ARG when that is not the context's device. */
 int mlkem_ctx_create(mlkem_ctx** out, int device, size_t chunk_items);
 void mlkem_ctx_destroy(mlkem_ctx* ctx);
 size_t mlkem_ctx_scratch_bytes(const mlkem_ctx* ctx);
