@@ -7,6 +7,7 @@
  * Error codes, messages and ownership follow ml_kem.c (init :1363, KEM_KeyGen :1233, KEM_Encaps :1257,
  * KEM_Decaps :1310); unlike the reference, error paths return zeroed structs instead of uninitialised ones.
  */
+#define _DEFAULT_SOURCE   /* explicit_bzero */
 #include "../../include/mlkem_compat.h"
 #include "../../include/mlkem_batch.h"
 
@@ -39,6 +40,12 @@ static unsigned char* narrow(const union byte* src, size_t n) {
     unsigned char* b = (unsigned char*)malloc(n ? n : 1);
     if (b) for (size_t i = 0; i < n; i++) b[i] = (unsigned char)src[i].e;   /* upper 24 bits are never read */
     return b;
+}
+/* packed staging copies of keys and shared secrets are zeroed before they are released */
+static void wipe_free(unsigned char* p, size_t n) {
+    if (!p) return;
+    explicit_bzero(p, n);
+    free(p);
 }
 static int engine_failed(const char* where, int rc) {
     if (rc == 0) return 0;
@@ -79,7 +86,7 @@ struct PKE KEM_KeyGen(const struct PARAMS* params) {
         result.ek_len = ek_len;
         result.dk_len = dk_len;
     }
-    free(ek); free(dk);
+    free(ek); wipe_free(dk, dk_len);
     return result;
 }
 
@@ -108,6 +115,7 @@ struct KEM KEM_Encaps(const struct PARAMS* params, const union byte* ek, unsigne
         result.c_len = c_len;
     }
     free(pek); free(c);
+    explicit_bzero(K, sizeof K);
     return result;
 }
 
@@ -140,7 +148,8 @@ union byte* KEM_Decaps(const struct PARAMS* params, const union byte* dk, unsign
             result = widen(K, 32);
         }
     }
-    free(pdk); free(pc);
+    wipe_free(pdk, dk_len); free(pc);
+    explicit_bzero(K, sizeof K);
     return result;
 }
 

@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <string.h>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -173,7 +174,10 @@ void mlkem_ctx_destroy(mlkem_ctx* ctx) {
             if (ctx->ws.ev_free[b]) (void)hipEventDestroy(ctx->ws.ev_free[b]);
         }
     }
-    if (ctx->scratch) (void)hipFree(ctx->scratch);
+    if (ctx->scratch) {
+        (void)hipMemset(ctx->scratch, 0, ctx->scratch_bytes);   // r, m', K', K-bar, PRF output: secret-dependent intermediates
+        (void)hipFree(ctx->scratch);
+    }
     delete ctx;
     if (prev >= 0) (void)hipSetDevice(prev);
 }
@@ -402,21 +406,41 @@ namespace {
 std::mutex g_host_mu;
 mlkem_ctx* g_host_ctx = nullptr;
 
-int host_ctx(mlkem_ctx** out) {
+// makes the host context's device current for the duration of a host-pointer call and restores the caller's afterwards
+struct DeviceGuard {
+    int prev = -1;
+    void enter(int dev) {
+        int cur = -1;
+        if (hipGetDevice(&cur) == hipSuccess && cur != dev && hipSetDevice(dev) == hipSuccess) prev = cur;
+    }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+// the host-pointer entry points share one lazily created context on the device that is current at the first call
+int host_ctx(mlkem_ctx** out, DeviceGuard& guard) {
     if (!g_host_ctx) {
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess) dev = 0;
         int rc = mlkem_ctx_create(&g_host_ctx, dev, (size_t)1 << 16);
         if (rc) return rc;
     }
+    guard.enter(g_host_ctx->device);
     *out = g_host_ctx;
     return MLKEM_OK;
 }
 
-struct DevBuf {
+struct DevBuf {   // device staging of a host-pointer call; zeroed before it is freed (seeds, keys and shared secrets pass through)
     void* p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
-    int alloc(size_t bytes) { return hip_ok(hipMalloc(&p, bytes ? bytes : 16), "hipMalloc") ? MLKEM_OK : MLKEM_ERR_ALLOC; }
+    size_t size = 0;
+    ~DevBuf() {
+        if (!p) return;
+        (void)hipMemset(p, 0, size);
+        (void)hipFree(p);
+    }
+    int alloc(size_t bytes) {
+        size = bytes ? bytes : 16;
+        return hip_ok(hipMalloc(&p, size), "hipMalloc") ? MLKEM_OK : MLKEM_ERR_ALLOC;
+    }
     template <class T> T* as() { return static_cast<T*>(p); }
 };
 
@@ -430,7 +454,8 @@ int mlkem_keygen(int set, size_t n, const uint8_t* d, const uint8_t* z, uint8_t*
     if (n && (!d || !z || !ek || !dk)) return MLKEM_ERR_ARG;
     std::lock_guard<std::mutex> lock(g_host_mu);
     mlkem_ctx* ctx;
-    int rc = host_ctx(&ctx);
+    DeviceGuard guard;
+    int rc = host_ctx(&ctx, guard);
     if (rc) return rc;
     if (n == 0) return MLKEM_OK;
     DevBuf bd, bz, bek, bdk;
@@ -450,7 +475,8 @@ int mlkem_encaps(int set, size_t n, const uint8_t* ek, const uint8_t* m, uint8_t
     if (n && (!ek || !m || !c || !K)) return MLKEM_ERR_ARG;
     std::lock_guard<std::mutex> lock(g_host_mu);
     mlkem_ctx* ctx;
-    int rc = host_ctx(&ctx);
+    DeviceGuard guard;
+    int rc = host_ctx(&ctx, guard);
     if (rc) return rc;
     if (n == 0) return MLKEM_OK;
     DevBuf bek, bm, bc, bK;
@@ -470,7 +496,8 @@ int mlkem_decaps(int set, size_t n, const uint8_t* dk, const uint8_t* c, uint8_t
     if (n && (!dk || !c || !K)) return MLKEM_ERR_ARG;
     std::lock_guard<std::mutex> lock(g_host_mu);
     mlkem_ctx* ctx;
-    int rc = host_ctx(&ctx);
+    DeviceGuard guard;
+    int rc = host_ctx(&ctx, guard);
     if (rc) return rc;
     if (n == 0) return MLKEM_OK;
     DevBuf bdk, bc, bK, bs;
@@ -488,7 +515,8 @@ static int host_ntt(bool inverse, size_t n, const uint16_t* in, uint16_t* out) {
     if (n && (!in || !out)) return MLKEM_ERR_ARG;
     std::lock_guard<std::mutex> lock(g_host_mu);
     mlkem_ctx* ctx;
-    int rc = host_ctx(&ctx);
+    DeviceGuard guard;
+    int rc = host_ctx(&ctx, guard);
     if (rc) return rc;
     if (n == 0) return MLKEM_OK;
     DevBuf bi, bo;
@@ -507,7 +535,8 @@ int mlkem_sample_ntt(size_t n, const uint8_t* seeds34, uint16_t* a_hat) {
     if (n && (!seeds34 || !a_hat)) return MLKEM_ERR_ARG;
     std::lock_guard<std::mutex> lock(g_host_mu);
     mlkem_ctx* ctx;
-    int rc = host_ctx(&ctx);
+    DeviceGuard guard;
+    int rc = host_ctx(&ctx, guard);
     if (rc) return rc;
     if (n == 0) return MLKEM_OK;
     DevBuf bi, bo;
@@ -521,7 +550,8 @@ int mlkem_sample_cbd(int eta, size_t n, const uint8_t* bytes, uint16_t* f) {
     if ((eta != 2 && eta != 3) || (n && (!bytes || !f))) return MLKEM_ERR_ARG;
     std::lock_guard<std::mutex> lock(g_host_mu);
     mlkem_ctx* ctx;
-    int rc = host_ctx(&ctx);
+    DeviceGuard guard;
+    int rc = host_ctx(&ctx, guard);
     if (rc) return rc;
     if (n == 0) return MLKEM_OK;
     DevBuf bi, bo;
@@ -536,7 +566,8 @@ int mlkem_keccak_sponge(unsigned rate, size_t n, const uint8_t* padded, unsigned
     if (n && (!padded || !out)) return MLKEM_ERR_ARG;
     std::lock_guard<std::mutex> lock(g_host_mu);
     mlkem_ctx* ctx;
-    int rc = host_ctx(&ctx);
+    DeviceGuard guard;
+    int rc = host_ctx(&ctx, guard);
     if (rc) return rc;
     if (n == 0) return MLKEM_OK;
     const size_t in_bytes = n * (size_t)nblocks * rate, ostride = ((size_t)outlen + 3) & ~(size_t)3;
@@ -580,8 +611,10 @@ int stream_op(size_t n, size_t chunk, const std::vector<Span>& spans, Launch lau
     auto cleanup = [&]() {
         for (auto& s : slot) {
             if (s.st) (void)hipStreamSynchronize(s.st);
-            for (void* p : s.dev) if (p) (void)hipFree(p);
-            for (void* p : s.pin) if (p) (void)hipHostFree(p);
+            for (size_t j = 0; j < s.dev.size(); j++) {   // staging buffers carry seeds / keys / shared secrets: zero, then free
+                if (s.dev[j]) { (void)hipMemset(s.dev[j], 0, chunk * spans[j].bytes); (void)hipFree(s.dev[j]); }
+                if (s.pin[j]) { explicit_bzero(s.pin[j], chunk * spans[j].bytes); (void)hipHostFree(s.pin[j]); }
+            }
             if (s.ctx) mlkem_ctx_destroy(s.ctx);
             if (s.st) (void)hipStreamDestroy(s.st);
         }
@@ -675,8 +708,11 @@ int mlkem_keygen_random(int set, size_t n, uint8_t* ek, uint8_t* dk) {
     ParamSet p;
     if (!param_set(set, p)) return MLKEM_ERR_PARAM_SET;
     std::vector<uint8_t> d(n * 32 + 1), z(n * 32 + 1);
-    if (!fill_random(d.data(), n * 32) || !fill_random(z.data(), n * 32)) return MLKEM_ERR_RNG;
-    return mlkem_keygen(set, n, d.data(), z.data(), ek, dk);
+    int rc = MLKEM_ERR_RNG;
+    if (fill_random(d.data(), n * 32) && fill_random(z.data(), n * 32)) rc = mlkem_keygen(set, n, d.data(), z.data(), ek, dk);
+    explicit_bzero(d.data(), d.size());
+    explicit_bzero(z.data(), z.size());
+    return rc;
 }
 
 int mlkem_encaps_random(int set, size_t n, const uint8_t* ek, unsigned ek_len, uint8_t* c, uint8_t* K) {
@@ -684,8 +720,10 @@ int mlkem_encaps_random(int set, size_t n, const uint8_t* ek, unsigned ek_len, u
     if (!param_set(set, p)) return MLKEM_ERR_PARAM_SET;
     if (ek_len != p.ek_len) return MLKEM_ERR_LENGTH;   // ml_kem.c:1267-1271; the modulus check that follows is a no-op (F3)
     std::vector<uint8_t> m(n * 32 + 1);
-    if (!fill_random(m.data(), n * 32)) return MLKEM_ERR_RNG;
-    return mlkem_encaps(set, n, ek, m.data(), c, K);
+    int rc = MLKEM_ERR_RNG;
+    if (fill_random(m.data(), n * 32)) rc = mlkem_encaps(set, n, ek, m.data(), c, K);
+    explicit_bzero(m.data(), m.size());
+    return rc;
 }
 
 }   // extern "C"
