@@ -237,10 +237,14 @@ k_encrypt(size_t n, const uint8_t* __restrict__ ek, size_t ek_stride, const uint
         diff |= emit_compressed<DV, COMPARE>(L.cbuf, acc, COMPARE ? nullptr : my_c + K * 32 * DU, cv_ref);
     }
     if constexpr (COMPARE) {
-        const bool mismatch = __ballot(diff != 0) != 0;
+        // both candidates are read and blended by mask: neither a branch nor an address depends on whether the
+        // ciphertext matched (the reference's early-exit compare, ml_kem.c:1206-1215, leaks it; implicit rejection
+        // is meant to hide it)
+        const uint32_t reject = __ballot(diff != 0) != 0 ? 0xFFFFFFFFu : 0u;
         if (l < 8) {
-            const uint32_t* src = reinterpret_cast<const uint32_t*>((mismatch ? Kbar : Kp) + item * 32);
-            reinterpret_cast<uint32_t*>(Kout + item * 32)[l] = src[l];
+            const uint32_t kp = reinterpret_cast<const uint32_t*>(Kp + item * 32)[l];
+            const uint32_t kb = reinterpret_cast<const uint32_t*>(Kbar + item * 32)[l];
+            reinterpret_cast<uint32_t*>(Kout + item * 32)[l] = (kp & ~reject) | (kb & reject);
         }
     }
 }
