@@ -15,7 +15,10 @@
 
 namespace mlkem {
 
-constexpr int ARITH_WAVES = 4;   // waves per workgroup (each fully independent)
+#ifndef MLKEM_ARITH_WAVES
+#define MLKEM_ARITH_WAVES 4
+#endif
+constexpr int ARITH_WAVES = MLKEM_ARITH_WAVES;   // waves per workgroup (each fully independent)
 #ifndef MLKEM_ARITH_MINWAVES
 #define MLKEM_ARITH_MINWAVES 1   // __launch_bounds__ second argument of the K-PKE kernels (register budget knob)
 #endif
