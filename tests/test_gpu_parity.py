@@ -233,6 +233,37 @@ def test_k_pke_alone_vs_oracle(engines, torch, oracle, pset):
     assert (host(ek2) == ekh).all() and (host(dk2)[:, : 384 * e.k] == dkh).all()
 
 
+def test_random_shapes_vs_oracle(pkg, torch, oracle):
+    """Seeded random cases: parameter set, batch size, chunk size (chunk / h-chunk / wave boundaries fall anywhere),
+    tampered ciphertext positions, corrupted dk hashes -- every output byte against the oracle."""
+    rng = np.random.default_rng(20260401)
+    for case in range(10):
+        pset = int(rng.choice(SETS))
+        n = int(rng.integers(1, 600))
+        chunk = int(rng.choice([64, 100, 192, 1000]))
+        ekl, dkl, cl = SIZES[pset]
+        e = pkg.MLKEM(pset, device=0, chunk_items=chunk)
+        d, z, m = seeds(f"rnd-d{case}", n, pset), seeds(f"rnd-z{case}", n, pset), seeds(f"rnd-m{case}", n, pset)
+        ek, dk = e.keygen(dev(torch, d), dev(torch, z))
+        c, K = e.encaps(ek, dev(torch, m))
+        cb, dkb = host(c).copy(), host(dk).copy()
+        bad_c = rng.choice(n, size=max(1, n // 7), replace=False)
+        cb[bad_c, rng.integers(0, cl, bad_c.size)] ^= rng.integers(1, 256, bad_c.size).astype(np.uint8)
+        bad_h = rng.choice(n, size=max(1, n // 11), replace=False)
+        dkb[bad_h, dkl - 64 + rng.integers(0, 32, bad_h.size)] ^= 0x40
+        Kd, st = e.decaps(dev(torch, dkb), dev(torch, cb))
+        ek_o, dk_o = oracle.keygen(pset, d, z)
+        c_o, K_o = oracle.encaps(pset, ek_o, m)
+        Kd_o, st_o = oracle.decaps(pset, dkb, cb)
+        assert (host(ek) == ek_o).all() and (host(dk) == dk_o).all(), (case, pset, n, chunk)
+        assert (host(c) == c_o).all() and (host(K) == K_o).all(), (case, pset, n, chunk)
+        sth = host(st)
+        assert (sth == st_o).all() and set(np.nonzero(sth)[0]) == set(bad_h.tolist()), (case, pset, n, chunk)
+        ok = st_o == 0
+        assert (host(Kd)[ok] == Kd_o[ok]).all(), (case, pset, n, chunk)
+        e.close()
+
+
 def test_empty_batches(engines, torch):
     e = engines[768]
     u8 = torch.uint8
