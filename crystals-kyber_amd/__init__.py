@@ -34,7 +34,7 @@ ABI_SYMBOLS = (
     "mlkem_keygen", "mlkem_encaps", "mlkem_decaps", "mlkem_ntt", "mlkem_intt", "mlkem_keccak_sponge",
     "mlkem_sample_ntt", "mlkem_sample_cbd",
     "mlkem_keygen_random", "mlkem_encaps_random",
-    "mlkem_cells_to_bytes_dev", "mlkem_bytes_to_cells_dev", "mlkem_keygen_stream", "mlkem_encaps_stream", "mlkem_decaps_stream",
+    "mlkem_cells_to_bytes_dev", "mlkem_bytes_to_cells_dev", "mlkem_keygen_stream", "mlkem_encaps_stream", "mlkem_decaps_stream", "mlkem_stream_release",
 )
 SHIM_SYMBOLS = ("init", "KEM_KeyGen", "KEM_Encaps", "KEM_Decaps", "ml_errno", "sha3_b", "sha3_h", "sha3_s", "h2b", "b2h",
                 "SampleNTT", "SamplePolyCBD", "NTT", "InverseNTT")

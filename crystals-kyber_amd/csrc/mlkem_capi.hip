@@ -15,6 +15,7 @@
 #include <string.h>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 using namespace mlkem;
@@ -592,78 +593,140 @@ namespace {
 
 struct Span { const void* in; void* out; size_t bytes; };   // per-item bytes; exactly one of in/out is set
 
+// The staging copies between the caller's pageable memory and the pinned buffers are the bottleneck of the streaming
+// front-end (a single memcpy thread moves ~10 GB/s, PCIe Gen5 x16 ~50): large copies are split over a few threads.
+void par_memcpy(void* dst, const void* src, size_t bytes) {
+    constexpr size_t MIN_PER_THREAD = (size_t)2 << 20;
+    unsigned hw = std::thread::hardware_concurrency();
+    size_t nt = bytes / MIN_PER_THREAD;
+    if (nt > 8) nt = 8;
+    if (hw && nt > hw) nt = hw;
+    if (nt <= 1) {
+        memcpy(dst, src, bytes);
+        return;
+    }
+    const size_t per = ((bytes + nt - 1) / nt + 63) & ~(size_t)63;   // slice t covers [t*per, min((t+1)*per, bytes))
+    std::vector<std::thread> th;
+    for (size_t t = 1; t * per < bytes; t++) {
+        const size_t off = t * per, len = bytes - off < per ? bytes - off : per;
+        th.emplace_back([=]() { memcpy(static_cast<uint8_t*>(dst) + off, static_cast<const uint8_t*>(src) + off, len); });
+    }
+    memcpy(dst, src, per < bytes ? per : bytes);
+    for (auto& x : th) x.join();
+}
+
+// A slot = stream + engine context + per-span device and pinned staging buffers.  The two slots live in a process-wide
+// cache and are reused by later calls (pinning host memory costs about as much as copying it once, so per-call
+// allocation used to dominate large chunks); buffers only grow, the context is recreated when the chunk size or the
+// device changes.  mlkem_stream_release() zeroes and frees everything.
+struct StageBuf {
+    void* dev = nullptr;
+    void* pin = nullptr;
+    size_t cap = 0;
+};
 struct StreamSlot {
     hipStream_t st = nullptr;
     mlkem_ctx* ctx = nullptr;
-    std::vector<void*> dev, pin;
+    size_t ctx_chunk = 0;
+    int device = -1;
+    std::vector<StageBuf> buf;
     size_t pending = 0, pending_off = 0;   // items whose outputs still sit in the pinned buffers
 };
+std::mutex g_stream_mu;
+StreamSlot g_slot[2];
+
+void slot_release(StreamSlot& s) {
+    if (s.st) (void)hipStreamSynchronize(s.st);
+    for (StageBuf& b : s.buf) {   // staging buffers carry seeds / keys / shared secrets: zero, then free
+        if (b.dev) { (void)hipMemset(b.dev, 0, b.cap); (void)hipFree(b.dev); }
+        if (b.pin) { explicit_bzero(b.pin, b.cap); (void)hipHostFree(b.pin); }
+    }
+    s.buf.clear();
+    if (s.ctx) mlkem_ctx_destroy(s.ctx);
+    if (s.st) (void)hipStreamDestroy(s.st);
+    s = StreamSlot();
+}
+
+int slot_prepare(StreamSlot& s, int dev, size_t chunk, const std::vector<Span>& spans) {
+    if (s.device != dev && s.device >= 0) slot_release(s);
+    s.device = dev;
+    if (!s.st && !hip_ok(hipStreamCreateWithFlags(&s.st, hipStreamNonBlocking), "hipStreamCreate")) return MLKEM_ERR_NO_DEVICE;
+    if (!s.ctx || s.ctx_chunk != chunk) {
+        if (s.ctx) mlkem_ctx_destroy(s.ctx);
+        s.ctx = nullptr;
+        int rc = mlkem_ctx_create(&s.ctx, dev, chunk);
+        if (rc) return rc;
+        s.ctx_chunk = chunk;
+    }
+    if (s.buf.size() < spans.size()) s.buf.resize(spans.size());
+    for (size_t j = 0; j < spans.size(); j++) {
+        StageBuf& b = s.buf[j];
+        const size_t need = chunk * spans[j].bytes;
+        if (b.cap >= need) continue;
+        if (b.dev) { (void)hipMemset(b.dev, 0, b.cap); (void)hipFree(b.dev); b.dev = nullptr; }
+        if (b.pin) { explicit_bzero(b.pin, b.cap); (void)hipHostFree(b.pin); b.pin = nullptr; }
+        b.cap = 0;
+        if (!hip_ok(hipMalloc(&b.dev, need), "hipMalloc")) return MLKEM_ERR_ALLOC;
+        if (!hip_ok(hipHostMalloc(&b.pin, need, hipHostMallocDefault), "hipHostMalloc")) return MLKEM_ERR_ALLOC;
+        b.cap = need;
+    }
+    s.pending = 0;
+    return MLKEM_OK;
+}
 
 template <class Launch>
 int stream_op(size_t n, size_t chunk, const std::vector<Span>& spans, Launch launch) {
     if (n == 0) return MLKEM_OK;
-    if (chunk == 0) chunk = (size_t)1 << 16;
+    if (chunk == 0) chunk = (size_t)1 << 14;   // measured best on MI355X (tools/stream_bench.py)
     if (chunk > n) chunk = n;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return MLKEM_ERR_NO_DEVICE;
-    StreamSlot slot[2];
-    int rc = MLKEM_OK;
-    auto cleanup = [&]() {
-        for (auto& s : slot) {
-            if (s.st) (void)hipStreamSynchronize(s.st);
-            for (size_t j = 0; j < s.dev.size(); j++) {   // staging buffers carry seeds / keys / shared secrets: zero, then free
-                if (s.dev[j]) { (void)hipMemset(s.dev[j], 0, chunk * spans[j].bytes); (void)hipFree(s.dev[j]); }
-                if (s.pin[j]) { explicit_bzero(s.pin[j], chunk * spans[j].bytes); (void)hipHostFree(s.pin[j]); }
-            }
-            if (s.ctx) mlkem_ctx_destroy(s.ctx);
-            if (s.st) (void)hipStreamDestroy(s.st);
-        }
-    };
+    std::lock_guard<std::mutex> lock(g_stream_mu);
     const int nslots = n > chunk ? 2 : 1;
-    for (int k = 0; k < nslots && rc == MLKEM_OK; k++) {
-        StreamSlot& s = slot[k];
-        if (!hip_ok(hipStreamCreateWithFlags(&s.st, hipStreamNonBlocking), "hipStreamCreate")) { rc = MLKEM_ERR_NO_DEVICE; break; }
-        rc = mlkem_ctx_create(&s.ctx, dev, chunk);
-        for (const Span& sp : spans) {
-            void *d = nullptr, *p = nullptr;
-            if (rc == MLKEM_OK && !hip_ok(hipMalloc(&d, chunk * sp.bytes), "hipMalloc")) rc = MLKEM_ERR_ALLOC;
-            if (rc == MLKEM_OK && !hip_ok(hipHostMalloc(&p, chunk * sp.bytes, hipHostMallocDefault), "hipHostMalloc")) rc = MLKEM_ERR_ALLOC;
-            s.dev.push_back(d);
-            s.pin.push_back(p);
-        }
-    }
+    int rc = MLKEM_OK;
+    for (int k = 0; k < nslots && rc == MLKEM_OK; k++) rc = slot_prepare(g_slot[k], dev, chunk, spans);
     auto drain = [&](StreamSlot& s) -> int {   // wait for the slot and hand its outputs to the caller
         if (!s.pending) return MLKEM_OK;
         if (!hip_ok(hipStreamSynchronize(s.st), "hipStreamSynchronize")) return MLKEM_ERR_NO_DEVICE;
         for (size_t j = 0; j < spans.size(); j++)
-            if (spans[j].out) memcpy(static_cast<uint8_t*>(spans[j].out) + s.pending_off * spans[j].bytes, s.pin[j], s.pending * spans[j].bytes);
+            if (spans[j].out) par_memcpy(static_cast<uint8_t*>(spans[j].out) + s.pending_off * spans[j].bytes, s.buf[j].pin, s.pending * spans[j].bytes);
         s.pending = 0;
         return MLKEM_OK;
     };
     size_t i = 0;
+    std::vector<void*> devp(spans.size());
     for (size_t off = 0; off < n && rc == MLKEM_OK; off += chunk, i++) {
-        StreamSlot& s = slot[i % nslots];
+        StreamSlot& s = g_slot[i % nslots];
         const size_t cnt = n - off < chunk ? n - off : chunk;
         if ((rc = drain(s)) != MLKEM_OK) break;
-        for (size_t j = 0; j < spans.size() && rc == MLKEM_OK; j++)
+        for (size_t j = 0; j < spans.size() && rc == MLKEM_OK; j++) {
+            devp[j] = s.buf[j].dev;
             if (spans[j].in) {
-                memcpy(s.pin[j], static_cast<const uint8_t*>(spans[j].in) + off * spans[j].bytes, cnt * spans[j].bytes);
-                if (!hip_ok(hipMemcpyAsync(s.dev[j], s.pin[j], cnt * spans[j].bytes, hipMemcpyHostToDevice, s.st), "H2D")) rc = MLKEM_ERR_NO_DEVICE;
+                par_memcpy(s.buf[j].pin, static_cast<const uint8_t*>(spans[j].in) + off * spans[j].bytes, cnt * spans[j].bytes);
+                if (!hip_ok(hipMemcpyAsync(s.buf[j].dev, s.buf[j].pin, cnt * spans[j].bytes, hipMemcpyHostToDevice, s.st), "H2D")) rc = MLKEM_ERR_NO_DEVICE;
             }
-        if (rc == MLKEM_OK) rc = launch(s.ctx, cnt, s.dev, s.st);
+        }
+        if (rc == MLKEM_OK) rc = launch(s.ctx, cnt, devp, s.st);
         for (size_t j = 0; j < spans.size() && rc == MLKEM_OK; j++)
-            if (spans[j].out && !hip_ok(hipMemcpyAsync(s.pin[j], s.dev[j], cnt * spans[j].bytes, hipMemcpyDeviceToHost, s.st), "D2H")) rc = MLKEM_ERR_NO_DEVICE;
+            if (spans[j].out && !hip_ok(hipMemcpyAsync(s.buf[j].pin, s.buf[j].dev, cnt * spans[j].bytes, hipMemcpyDeviceToHost, s.st), "D2H")) rc = MLKEM_ERR_NO_DEVICE;
         s.pending = cnt;
         s.pending_off = off;
     }
-    for (int k = 0; k < nslots && rc == MLKEM_OK; k++) rc = drain(slot[k]);
-    cleanup();
+    for (int k = 0; k < nslots && rc == MLKEM_OK; k++) rc = drain(g_slot[k]);
+    if (rc != MLKEM_OK) {   // leave nothing half-done behind
+        for (int k = 0; k < 2; k++) slot_release(g_slot[k]);
+    }
     return rc;
 }
 
 }   // namespace
 
 extern "C" {
+
+void mlkem_stream_release(void) {
+    std::lock_guard<std::mutex> lock(g_stream_mu);
+    for (int k = 0; k < 2; k++) slot_release(g_slot[k]);
+}
 
 int mlkem_keygen_stream(int set, size_t n, const uint8_t* d, const uint8_t* z, uint8_t* ek, uint8_t* dk, size_t chunk_items) {
     ParamSet p;

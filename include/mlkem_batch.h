@@ -158,10 +158,13 @@ int mlkem_keccak_sponge(unsigned rate, size_t n, const uint8_t* padded, unsigned
 int mlkem_cells_to_bytes_dev(mlkem_ctx* ctx, size_t n_cells, const uint32_t* cells, uint8_t* bytes, void* stream);
 int mlkem_bytes_to_cells_dev(mlkem_ctx* ctx, size_t n_cells, const uint8_t* bytes, uint32_t* cells, void* stream);
 /* Host-resident batches of any size: double-buffered pinned staging, H2D / kernels / D2H of chunk i overlap the host
- * copies of chunk i+1 (chunk_items = 0 -> 2^16).  Same results as the plain host-pointer calls; PCIe-bound. */
+ * copies of chunk i+1 (chunk_items = 0 -> 2^14).  Same results as the plain host-pointer calls; PCIe-bound. */
 int mlkem_keygen_stream(int param_set, size_t n, const uint8_t* d, const uint8_t* z, uint8_t* ek, uint8_t* dk, size_t chunk_items);
 int mlkem_encaps_stream(int param_set, size_t n, const uint8_t* ek, const uint8_t* m, uint8_t* c, uint8_t* K, size_t chunk_items);
 int mlkem_decaps_stream(int param_set, size_t n, const uint8_t* dk, const uint8_t* c, uint8_t* K, int32_t* status, size_t chunk_items);
+/* The streaming calls keep two slots (stream, context, pinned + device staging buffers) cached between calls;
+ * this zeroes and frees them. */
+void mlkem_stream_release(void);
 
 /* ---- randomised wrappers: seeds drawn on the host with getrandom(2) ---------------- */
 /* replaces KEM_KeyGen(params)  ml_kem.c:1233-1252 for n key pairs */

@@ -24,7 +24,7 @@ ekh, dkh, mh = ek.cpu().numpy(), dk.cpu().numpy(), m.cpu().numpy()
 c, K = np.zeros((n, 1088), np.uint8), np.zeros((n, 32), np.uint8)
 K2, st = np.zeros((n, 32), np.uint8), np.ones(n, np.int32)
 res = {}
-for chunk in (1 << 15, 1 << 16, 1 << 17):
+for chunk in (1 << 13, 1 << 14, 1 << 15, 1 << 16, 1 << 17):
     lib.mlkem_encaps_stream(768, n, ekh.ctypes.data, mh.ctypes.data, c.ctypes.data, K.ctypes.data, chunk)   # warm
     t0 = time.perf_counter()
     assert lib.mlkem_encaps_stream(768, n, ekh.ctypes.data, mh.ctypes.data, c.ctypes.data, K.ctypes.data, chunk) == 0
