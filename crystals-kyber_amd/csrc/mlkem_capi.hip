@@ -449,10 +449,14 @@ struct DevBuf {   // device staging of a host-pointer call; zeroed before it is 
 
 extern "C" {
 
+// batches of HOST_STREAM_MIN items and more go through the double-buffered streaming front-end (same results, PCIe overlap)
+constexpr size_t HOST_STREAM_MIN = (size_t)1 << 15;
+
 int mlkem_keygen(int set, size_t n, const uint8_t* d, const uint8_t* z, uint8_t* ek, uint8_t* dk) {
     ParamSet p;
     if (!param_set(set, p)) return MLKEM_ERR_PARAM_SET;
     if (n && (!d || !z || !ek || !dk)) return MLKEM_ERR_ARG;
+    if (n >= HOST_STREAM_MIN) return mlkem_keygen_stream(set, n, d, z, ek, dk, 0);
     std::lock_guard<std::mutex> lock(g_host_mu);
     mlkem_ctx* ctx;
     DeviceGuard guard;
@@ -474,6 +478,7 @@ int mlkem_encaps(int set, size_t n, const uint8_t* ek, const uint8_t* m, uint8_t
     ParamSet p;
     if (!param_set(set, p)) return MLKEM_ERR_PARAM_SET;
     if (n && (!ek || !m || !c || !K)) return MLKEM_ERR_ARG;
+    if (n >= HOST_STREAM_MIN) return mlkem_encaps_stream(set, n, ek, m, c, K, 0);
     std::lock_guard<std::mutex> lock(g_host_mu);
     mlkem_ctx* ctx;
     DeviceGuard guard;
@@ -495,6 +500,11 @@ int mlkem_decaps(int set, size_t n, const uint8_t* dk, const uint8_t* c, uint8_t
     ParamSet p;
     if (!param_set(set, p)) return MLKEM_ERR_PARAM_SET;
     if (n && (!dk || !c || !K)) return MLKEM_ERR_ARG;
+    if (n >= HOST_STREAM_MIN) {
+        if (status) return mlkem_decaps_stream(set, n, dk, c, K, status, 0);
+        std::vector<int32_t> st(n);   // KEM_Decaps semantics (hash check) either way; the caller did not ask for the codes
+        return mlkem_decaps_stream(set, n, dk, c, K, st.data(), 0);
+    }
     std::lock_guard<std::mutex> lock(g_host_mu);
     mlkem_ctx* ctx;
     DeviceGuard guard;

@@ -353,6 +353,25 @@ def test_host_pointer_abi(pkg, torch, oracle):
     assert lib.mlkem_encaps_random(768, n, ek.ctypes.data, 1183, c.ctypes.data, K.ctypes.data) == -3
     Ko, sto = oracle.decaps(768, dk, c)
     assert (sto == 0).all() and (Ko == K).all()
+    # large host batches are routed through the streaming front-end: same bytes as the device-resident path
+    big = 33000
+    e = pkg.MLKEM(512, device=0)
+    db, zb, mb = seeds("host-bd", big, 5), seeds("host-bz", big, 5), seeds("host-bm", big, 5)
+    ekb, dkb = np.zeros((big, 800), np.uint8), np.zeros((big, 1632), np.uint8)
+    assert lib.mlkem_keygen(512, big, db.ctypes.data, zb.ctypes.data, ekb.ctypes.data, dkb.ctypes.data) == 0
+    cb, Kb = np.zeros((big, 768), np.uint8), np.zeros((big, 32), np.uint8)
+    assert lib.mlkem_encaps(512, big, ekb.ctypes.data, mb.ctypes.data, cb.ctypes.data, Kb.ctypes.data) == 0
+    cb[::1000, 3] ^= 1
+    Kdb = np.zeros((big, 32), np.uint8)
+    assert lib.mlkem_decaps(512, big, dkb.ctypes.data, cb.ctypes.data, Kdb.ctypes.data, None) == 0
+    ek_d, dk_d = e.keygen(dev(torch, db), dev(torch, zb))
+    cb[::1000, 3] ^= 1
+    c_d, K_d = e.encaps(ek_d, dev(torch, mb))
+    assert (host(ek_d) == ekb).all() and (host(dk_d) == dkb).all() and (host(c_d) == cb).all() and (host(K_d) == Kb).all()
+    same = (Kdb == Kb).all(axis=1)
+    assert not same[::1000].any() and same.sum() == big - len(range(0, big, 1000))
+    lib.mlkem_stream_release()
+    e.close()
 
 
 SHIM_TEST_C = r"""
