@@ -449,77 +449,18 @@ struct DevBuf {   // device staging of a host-pointer call; zeroed before it is 
 
 extern "C" {
 
-// batches of HOST_STREAM_MIN items and more go through the double-buffered streaming front-end (same results, PCIe overlap)
-constexpr size_t HOST_STREAM_MIN = (size_t)1 << 15;
-
+// The host-pointer KEM calls are the streaming front-end with its default chunking: one cached slot for small batches
+// (no allocation per call after the first), two double-buffered slots beyond one chunk.
 int mlkem_keygen(int set, size_t n, const uint8_t* d, const uint8_t* z, uint8_t* ek, uint8_t* dk) {
-    ParamSet p;
-    if (!param_set(set, p)) return MLKEM_ERR_PARAM_SET;
-    if (n && (!d || !z || !ek || !dk)) return MLKEM_ERR_ARG;
-    if (n >= HOST_STREAM_MIN) return mlkem_keygen_stream(set, n, d, z, ek, dk, 0);
-    std::lock_guard<std::mutex> lock(g_host_mu);
-    mlkem_ctx* ctx;
-    DeviceGuard guard;
-    int rc = host_ctx(&ctx, guard);
-    if (rc) return rc;
-    if (n == 0) return MLKEM_OK;
-    DevBuf bd, bz, bek, bdk;
-    if ((rc = bd.alloc(n * 32)) || (rc = bz.alloc(n * 32)) || (rc = bek.alloc(n * p.ek_len)) || (rc = bdk.alloc(n * p.dk_len))) return rc;
-    HIP_TRY(hipMemcpy(bd.p, d, n * 32, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(bz.p, z, n * 32, hipMemcpyHostToDevice));
-    rc = mlkem_keygen_dev(ctx, set, n, bd.as<uint8_t>(), bz.as<uint8_t>(), bek.as<uint8_t>(), bdk.as<uint8_t>(), nullptr);
-    if (rc) return rc;
-    HIP_TRY(hipMemcpy(ek, bek.p, n * p.ek_len, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(dk, bdk.p, n * p.dk_len, hipMemcpyDeviceToHost));
-    return MLKEM_OK;
+    return mlkem_keygen_stream(set, n, d, z, ek, dk, 0);
 }
-
 int mlkem_encaps(int set, size_t n, const uint8_t* ek, const uint8_t* m, uint8_t* c, uint8_t* K) {
-    ParamSet p;
-    if (!param_set(set, p)) return MLKEM_ERR_PARAM_SET;
-    if (n && (!ek || !m || !c || !K)) return MLKEM_ERR_ARG;
-    if (n >= HOST_STREAM_MIN) return mlkem_encaps_stream(set, n, ek, m, c, K, 0);
-    std::lock_guard<std::mutex> lock(g_host_mu);
-    mlkem_ctx* ctx;
-    DeviceGuard guard;
-    int rc = host_ctx(&ctx, guard);
-    if (rc) return rc;
-    if (n == 0) return MLKEM_OK;
-    DevBuf bek, bm, bc, bK;
-    if ((rc = bek.alloc(n * p.ek_len)) || (rc = bm.alloc(n * 32)) || (rc = bc.alloc(n * p.c_len)) || (rc = bK.alloc(n * 32))) return rc;
-    HIP_TRY(hipMemcpy(bek.p, ek, n * p.ek_len, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(bm.p, m, n * 32, hipMemcpyHostToDevice));
-    rc = mlkem_encaps_dev(ctx, set, n, bek.as<uint8_t>(), bm.as<uint8_t>(), bc.as<uint8_t>(), bK.as<uint8_t>(), nullptr);
-    if (rc) return rc;
-    HIP_TRY(hipMemcpy(c, bc.p, n * p.c_len, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(K, bK.p, n * 32, hipMemcpyDeviceToHost));
-    return MLKEM_OK;
+    return mlkem_encaps_stream(set, n, ek, m, c, K, 0);
 }
-
 int mlkem_decaps(int set, size_t n, const uint8_t* dk, const uint8_t* c, uint8_t* K, int32_t* status) {
-    ParamSet p;
-    if (!param_set(set, p)) return MLKEM_ERR_PARAM_SET;
-    if (n && (!dk || !c || !K)) return MLKEM_ERR_ARG;
-    if (n >= HOST_STREAM_MIN) {
-        if (status) return mlkem_decaps_stream(set, n, dk, c, K, status, 0);
-        std::vector<int32_t> st(n);   // KEM_Decaps semantics (hash check) either way; the caller did not ask for the codes
-        return mlkem_decaps_stream(set, n, dk, c, K, st.data(), 0);
-    }
-    std::lock_guard<std::mutex> lock(g_host_mu);
-    mlkem_ctx* ctx;
-    DeviceGuard guard;
-    int rc = host_ctx(&ctx, guard);
-    if (rc) return rc;
-    if (n == 0) return MLKEM_OK;
-    DevBuf bdk, bc, bK, bs;
-    if ((rc = bdk.alloc(n * p.dk_len)) || (rc = bc.alloc(n * p.c_len)) || (rc = bK.alloc(n * 32)) || (rc = bs.alloc(n * 4))) return rc;
-    HIP_TRY(hipMemcpy(bdk.p, dk, n * p.dk_len, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(bc.p, c, n * p.c_len, hipMemcpyHostToDevice));
-    rc = mlkem_decaps_dev(ctx, set, n, bdk.as<uint8_t>(), bc.as<uint8_t>(), bK.as<uint8_t>(), status ? bs.as<int32_t>() : nullptr, nullptr);
-    if (rc) return rc;
-    HIP_TRY(hipMemcpy(K, bK.p, n * 32, hipMemcpyDeviceToHost));
-    if (status) HIP_TRY(hipMemcpy(status, bs.p, n * 4, hipMemcpyDeviceToHost));
-    return MLKEM_OK;
+    if (status || n == 0) return mlkem_decaps_stream(set, n, dk, c, K, status, 0);
+    std::vector<int32_t> st(n);   // the caller did not ask for the hash-check codes; K does not depend on them
+    return mlkem_decaps_stream(set, n, dk, c, K, st.data(), 0);
 }
 
 static int host_ntt(bool inverse, size_t n, const uint16_t* in, uint16_t* out) {
@@ -661,7 +602,7 @@ int slot_prepare(StreamSlot& s, int dev, size_t chunk, const std::vector<Span>& 
     if (s.device != dev && s.device >= 0) slot_release(s);
     s.device = dev;
     if (!s.st && !hip_ok(hipStreamCreateWithFlags(&s.st, hipStreamNonBlocking), "hipStreamCreate")) return MLKEM_ERR_NO_DEVICE;
-    if (!s.ctx || s.ctx_chunk != chunk) {
+    if (!s.ctx || s.ctx_chunk < chunk) {   // a context serves any batch size; its chunk capacity only grows
         if (s.ctx) mlkem_ctx_destroy(s.ctx);
         s.ctx = nullptr;
         int rc = mlkem_ctx_create(&s.ctx, dev, chunk);

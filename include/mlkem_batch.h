@@ -141,7 +141,8 @@ int mlkem_keccak_sponge_dev(mlkem_ctx* ctx, unsigned rate, size_t n, const uint8
 int mlkem_sha3_pad_bits(const uint8_t* msg_bits, size_t nbits, int xof, unsigned rate, uint8_t* padded, size_t padded_cap);
 
 /* ---- batched KEM, host pointers (stage + run + synchronise) ----------------------------------------
- * Batches of 2^15 items and more are routed through the streaming front-end below (same results). */
+ * These are the streaming front-end below with its default chunking: staging buffers, stream and context are cached
+ * between calls (mlkem_stream_release() frees them), so a call allocates nothing after the first. */
 int mlkem_keygen(int param_set, size_t n, const uint8_t* d, const uint8_t* z, uint8_t* ek, uint8_t* dk);
 int mlkem_encaps(int param_set, size_t n, const uint8_t* ek, const uint8_t* m, uint8_t* c, uint8_t* K);
 int mlkem_decaps(int param_set, size_t n, const uint8_t* dk, const uint8_t* c, uint8_t* K, int32_t* status);
