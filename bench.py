@@ -35,7 +35,8 @@ import __graft_entry__ as ge  # noqa: E402
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 VALU_PEAK_LANE_OPS = 256 * 4 * 32 * 2.4e9   # 256 CU x 4 SIMD-32 x 2.4 GHz (one 32-bit integer op per lane-clock)
 BENCH_SEED = 0xC0FFEE
-ALGO_BYTES = {"kem768": 5856, "kem1024": 12768, "kem512": 6560, "ntt": 2048}   # SURVEY 8d / BASELINE.md section 4
+ALGO_BYTES = {"kem768": 5856, "kem1024": 12768, "kem512": 6560, "ntt": 2048,
+              "kem768_shared": 32 + 1088 + 32 + 1088 + 32}   # per pair: m, c, K (encaps) + c, K (decaps); the one key is read once   # SURVEY 8d / BASELINE.md section 4
 # 32-bit VALU lane-operations per unit, from the ISA of this build
 KECCAK_PERM_LANE_OPS = 24 * 180
 TIMING_PASSES = 3   # passes of the per-kernel HIP-event timing leg
@@ -148,8 +149,15 @@ def run_kem(args, pset, rank, world, device):
     K2 = torch.empty((n, 32), dtype=torch.uint8, device=device)
     st = torch.empty(n, dtype=torch.int32, device=device)
     timed_keygen = args.workload in ("kem1024", "kem512")
+    shared = args.workload == "kem768_shared"
+    lib, ctx = eng.lib, eng._ctx
 
     def step():
+        if shared:   # one server key for the whole batch (keys of item 0)
+            s = eng._stream()
+            eng._check(lib.mlkem_encaps_shared_dev(ctx, pset, n, ek.data_ptr(), m.data_ptr(), c.data_ptr(), K.data_ptr(), s))
+            eng._check(lib.mlkem_decaps_shared_dev(ctx, pset, n, dk.data_ptr(), c.data_ptr(), K2.data_ptr(), st.data_ptr(), s))
+            return
         if timed_keygen:
             eng.keygen(d, z, ek=ek, dk=dk)
         eng.encaps(ek, m, c=c, K=K)
@@ -171,7 +179,7 @@ def run_kem(args, pset, rank, world, device):
     ct = c.clone()
     idx = torch.arange(0, n, 1024, device=device)
     ct[idx, (idx * 13) % eng.c_len] ^= 2
-    Kt, stt = eng.decaps(dk, ct)
+    Kt, stt = eng.decaps_shared(dk[0], ct) if shared else eng.decaps(dk, ct)
     same = (Kt == K).all(dim=1)
     ok = ok and not bool(same[idx].any()) and int(same.sum()) == n - idx.numel() and int(stt.abs().max()) == 0
 
@@ -187,7 +195,10 @@ def run_kem(args, pset, rank, world, device):
         extra["kernels"] = rows
         extra["chunk_items"] = args.chunk or int(os.environ.get("MLKEM_CHUNK_ITEMS", 1 << 18))
         if world == 1 and not args.no_cpu:
-            extra["cpu_baseline"] = cpu_baseline(pset, ek, dk, m, c, K)
+            if shared:   # the reference has no shared-key path: every pair pays for the full key handling
+                extra["cpu_baseline"] = cpu_baseline(pset, ek[:1].expand(n, -1), dk[:1].expand(n, -1), m, c, K)
+            else:
+                extra["cpu_baseline"] = cpu_baseline(pset, ek, dk, m, c, K)
     eng.close()
     return elapsed, ok, extra
 
@@ -246,7 +257,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None, help="timed steps (default 5; 40 for the sub-millisecond NTT workload)")
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="kem768", choices=("kem768", "kem1024", "kem512", "ntt"))
+    ap.add_argument("--workload", default="kem768", choices=("kem768", "kem1024", "kem512", "ntt", "kem768_shared"))
     ap.add_argument("--batch", type=int, default=1 << 20, help="items per GPU per step (BASELINE: 2^20)")
     ap.add_argument("--chunk", type=int, default=0, help="engine chunk size in items (0 = library default)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
@@ -266,9 +277,12 @@ def main():
         wl = "configs[1]: batched forward+inverse NTT only, %d polynomials per GPU" % args.batch
         dtype = "f32 (exact integer arithmetic < 2^24), u16 I/O"
     else:
-        pset = {"kem768": 768, "kem1024": 1024, "kem512": 512}[args.workload]
+        pset = {"kem768": 768, "kem1024": 1024, "kem512": 512, "kem768_shared": 768}[args.workload]
         elapsed, ok, extra = run_kem(args, pset, rank, world, device)
-        if args.workload == "kem768":
+        if args.workload == "kem768_shared":
+            metric, unit = "ML-KEM-768 encaps+decaps/sec at batch 2^20, ONE key pair for the whole batch", "pairs/s"
+            wl = "extra (not a BASELINE config): ML-KEM-768 Encaps+Decaps of %d items to / under one key (mlkem_*_shared_dev)" % args.batch
+        elif args.workload == "kem768":
             metric, unit = "ML-KEM-768 encaps+decaps/sec at batch 2^20; achieved HBM GB/s vs peak", "pairs/s"
             wl = "configs[2]: ML-KEM-768 full Encaps+Decaps (KEM_Decaps incl. dk hash check), batch %d per GPU, keys from batch KeyGen (untimed)" % args.batch
         else:
@@ -308,7 +322,7 @@ def main():
         roofline["traffic"] = t["hbm_bytes_per_step_corrected"]
         roofline["traffic_note"] = "bytes per step from %s: (2*FETCH_SIZE + WRITE_SIZE)*1024; raw = %.3g" % (
             os.path.relpath(tpath, ROOT), t["hbm_bytes_per_step_raw"])
-    if args.workload != "ntt" and dom == "k_sample_main":
+    if args.workload in ("kem512", "kem768", "kem1024") and dom == "k_sample_main":
         # the dominant kernel's own HBM bytes per launch: per item it reads rho and r (32 B each) and
         # writes the k x k matrix (512 B per polynomial) and the PRF rows (128 B, 192 B for eta = 3)
         k = {"kem512": 2, "kem768": 3, "kem1024": 4}[args.workload]

@@ -27,6 +27,7 @@ ABI_SYMBOLS = (
     "mlkem_sizes", "mlkem_params", "mlkem_device_count", "mlkem_strerror", "mlkem_last_hip_error",
     "mlkem_ctx_create", "mlkem_ctx_destroy", "mlkem_ctx_scratch_bytes", "mlkem_timing_begin", "mlkem_timing_end",
     "mlkem_keygen_dev", "mlkem_encaps_dev", "mlkem_decaps_dev", "mlkem_encaps_status_dev", "mlkem_ctx_set_conformance",
+    "mlkem_encaps_shared_dev", "mlkem_decaps_shared_dev",
     "mlkem_pke_keygen_dev", "mlkem_pke_encrypt_dev", "mlkem_pke_decrypt_dev",
     "mlkem_ntt_dev", "mlkem_intt_dev", "mlkem_multiply_ntts_dev", "mlkem_sample_ntt_dev", "mlkem_sample_cbd_dev",
     "mlkem_compress_encode_dev", "mlkem_decode_decompress_dev",
@@ -75,6 +76,8 @@ def load_library():
     L.mlkem_decaps_dev.argtypes = [vp, i32, sz, vp, vp, vp, vp, vp]
     L.mlkem_encaps_status_dev.argtypes = [vp, i32, sz, vp, vp, vp, vp, vp, vp]
     L.mlkem_ctx_set_conformance.argtypes = [vp, i32]
+    L.mlkem_encaps_shared_dev.argtypes = [vp, i32, sz, vp, vp, vp, vp, vp]
+    L.mlkem_decaps_shared_dev.argtypes = [vp, i32, sz, vp, vp, vp, vp, vp]
     L.mlkem_pke_keygen_dev.argtypes = [vp, i32, sz, vp, vp, vp, vp]
     L.mlkem_pke_encrypt_dev.argtypes = [vp, i32, sz, vp, vp, vp, vp, vp]
     L.mlkem_pke_decrypt_dev.argtypes = [vp, i32, sz, vp, vp, vp, vp]
@@ -251,6 +254,31 @@ class MLKEM:
 
     def Decaps_internal(self, dk, c):
         return self.decaps(dk, c, hash_check=False)[0]
+
+    # -- shared-key batches: one ek / dk for all items ----------------------------------------------
+    def encaps_shared(self, ek, m):
+        """n encapsulations to ONE key: ek [ek_len] or [1,ek_len], m [n,32] -> c [n,c_len], K [n,32]; same bytes as
+        encaps() on the replicated key, H(ek) and the matrix computed once."""
+        u8 = self.torch.uint8
+        ek = self._dev(self.torch.as_tensor(ek).reshape(1, -1), u8, self.ek_len)
+        m = self._dev(m, u8, 32)
+        n = m.shape[0]
+        c, K = self._out(n, self.c_len), self._out(n, 32)
+        self._check(self.lib.mlkem_encaps_shared_dev(self._ctx, self.param_set, n, ek.data_ptr(), m.data_ptr(), c.data_ptr(),
+                                                     K.data_ptr(), self._stream()))
+        return c, K
+
+    def decaps_shared(self, dk, c, hash_check=True):
+        """n decapsulations under ONE key: dk [dk_len] or [1,dk_len], c [n,c_len] -> K [n,32], status [n] (0 / -5)."""
+        torch = self.torch
+        dk = self._dev(torch.as_tensor(dk).reshape(1, -1), torch.uint8, self.dk_len)
+        c = self._dev(c, torch.uint8, self.c_len)
+        n = c.shape[0]
+        K = self._out(n, 32)
+        status = torch.empty(n, dtype=torch.int32, device=self.device) if hash_check else None
+        self._check(self.lib.mlkem_decaps_shared_dev(self._ctx, self.param_set, n, dk.data_ptr(), c.data_ptr(), K.data_ptr(),
+                                                     status.data_ptr() if hash_check else None, self._stream()))
+        return K, status
 
     # -- K-PKE on its own (SURVEY 8a rows a21-a23) ---------------------------------------------------
     def PKE_KeyGen(self, d):

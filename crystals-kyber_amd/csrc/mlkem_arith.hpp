@@ -141,7 +141,9 @@ template <int K, int ETA1, int DU, int DV, bool COMPARE>
 __global__ void __launch_bounds__(WAVE * ARITH_WAVES, MLKEM_ARITH_MINWAVES)
 k_encrypt(size_t n, const uint8_t* __restrict__ ek, size_t ek_stride, const uint8_t* __restrict__ msg, const uint16_t* __restrict__ A,
           const uint8_t* __restrict__ prf, uint8_t* __restrict__ c_out, const uint8_t* __restrict__ c_in, const uint8_t* __restrict__ Kp,
-          const uint8_t* __restrict__ Kbar, uint8_t* __restrict__ Kout, int32_t* __restrict__ mod_status) {
+          const uint8_t* __restrict__ Kbar, uint8_t* __restrict__ Kout, int32_t* __restrict__ mod_status, size_t a_stride) {
+    // a_stride: uint16 elements between the matrices of consecutive items (K*K*256), or 0 when every item uses the same
+    // key and therefore the same matrix (shared-key batches: ek_stride is 0 as well)
     // mod_status (optional): per-item result of the FIPS 203 encapsulation-key modulus check, 0 or -4.  The reference's
     // own check can never fail (ml_kem.c:1273-1291, F3), so its callers pass nullptr.
     __shared__ ArithLds<K> lds_all[ARITH_WAVES];
@@ -152,7 +154,7 @@ k_encrypt(size_t n, const uint8_t* __restrict__ ek, size_t ek_stride, const uint
     constexpr unsigned PS = (ETA1 == 3) ? 192 : 128, CLEN = 32 * (DU * K + DV);
     const uint8_t* my_prf = prf + item * (size_t)((2 * K + 1) * PS);
     const uint8_t* my_ek = ek + item * ek_stride;
-    const uint16_t* my_A = A + item * (size_t)(K * K * 256);
+    const uint16_t* my_A = A + item * a_stride;
     uint8_t* my_c = COMPARE ? nullptr : c_out + item * CLEN;
     const uint8_t* my_cin = COMPARE ? c_in + item * CLEN : nullptr;
 

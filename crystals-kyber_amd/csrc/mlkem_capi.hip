@@ -234,6 +234,27 @@ int mlkem_keygen_dev(mlkem_ctx* ctx, int set, size_t n, const uint8_t* d, const 
     return MLKEM_OK;
 }
 
+// ---- shared-key batches ------------------------------------------------------------------------------------------
+int mlkem_encaps_shared_dev(mlkem_ctx* ctx, int set, size_t n, const uint8_t* ek, const uint8_t* m, uint8_t* c, uint8_t* K, void* stream) {
+    ParamSet p;
+    if (!param_set(set, p)) return MLKEM_ERR_PARAM_SET;
+    if (!ctx_ok(ctx) || (n && (!ek || !m || !c || !K))) return MLKEM_ERR_ARG;
+    if (!aligned16(ek) || !aligned16(m) || !aligned16(c) || !aligned16(K)) return MLKEM_ERR_ARG;
+    encaps_shared_dispatch(static_cast<hipStream_t>(stream), set, n, ek, m, c, K, ctx->ws);
+    HIP_TRY(hipGetLastError());
+    return MLKEM_OK;
+}
+int mlkem_decaps_shared_dev(mlkem_ctx* ctx, int set, size_t n, const uint8_t* dk, const uint8_t* c, uint8_t* K, int32_t* status,
+                            void* stream) {
+    ParamSet p;
+    if (!param_set(set, p)) return MLKEM_ERR_PARAM_SET;
+    if (!ctx_ok(ctx) || (n && (!dk || !c || !K))) return MLKEM_ERR_ARG;
+    if (!aligned16(dk) || !aligned16(c) || !aligned16(K) || (reinterpret_cast<uintptr_t>(status) & 3u)) return MLKEM_ERR_ARG;
+    decaps_shared_dispatch(static_cast<hipStream_t>(stream), set, n, dk, c, K, status, ctx->ws);
+    HIP_TRY(hipGetLastError());
+    return MLKEM_OK;
+}
+
 // ---- K-PKE on its own (ml_kem.c:651 / :776 / :942; static in the reference, reachable there through KeyGen_internal /
 // Encaps_internal / Decaps_internal and through the oracle's harness) ------------------------------------------------
 int mlkem_pke_keygen_dev(mlkem_ctx* ctx, int set, size_t n, const uint8_t* d, uint8_t* ek, uint8_t* dk_pke, void* stream) {

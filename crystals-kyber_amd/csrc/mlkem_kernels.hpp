@@ -348,6 +348,36 @@ __global__ void __launch_bounds__(WAVE, MLKEM_KECCAK_MINWAVES) k_hash_encaps(siz
 }
 
 // ------------------------------------------------------------------------------------------------
+// Shared-key batches (one ek / dk for all n items): H(ek) is computed once (k_hash_batch<0>, one item) and
+//   k_hash_g_shared  : (K_i, r_i) = G(m_i || h) per item (ml_kem.c:1113-1124) with the broadcast h
+//   k_status_fill    : KEM_Decaps' hash check (ml_kem.c:1336-1350) evaluated once: status[i] = (h_calc == h_stored) ? 0 : -5
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(WAVE, MLKEM_KECCAK_MINWAVES) k_hash_g_shared(size_t n, const uint8_t* __restrict__ m, const uint8_t* __restrict__ h,
+                                                                               uint8_t* __restrict__ Kout, uint8_t* __restrict__ r_ws) {
+    const size_t item = (size_t)blockIdx.x * WAVE + lane_id();
+    const size_t it = item < n ? item : n - 1;
+    uint32_t mm[8], hh[8], w[8];
+    load32(m, 32, it, mm);
+    load32(h, 0, 0, hh);
+    KeccakState s;
+    lane_G64(s, mm, hh);
+    if (item < n) {
+        MLKEM_STATE_WORDS8(s, 0, w)
+        store32(Kout, 32, item, w);
+        MLKEM_STATE_WORDS8(s, 8, w)
+        store32(r_ws, 32, item, w);
+    }
+}
+__global__ void __launch_bounds__(256) k_status_fill(size_t n, const uint8_t* __restrict__ h_calc, const uint8_t* __restrict__ h_stored,
+                                                     int32_t* __restrict__ status) {
+    uint32_t diff = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) diff |= reinterpret_cast<const uint32_t*>(h_calc)[i] ^ reinterpret_cast<const uint32_t*>(h_stored)[i];
+    const int32_t v = diff ? -5 : 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) status[i] = v;
+}
+
+// ------------------------------------------------------------------------------------------------
 // k_hash_decaps — KEM_Decaps hash check (ml_kem.c:1336-1350) and Decaps_internal's hashing
 // (ml_kem.c:1187-1202): status = (H(dk.ek) == dk.h) ? 0 : -5 ; (K', r') = G(m' || dk.h) ; Kbar = J(dk.z || c)
 // J is SHAKE128 in the reference (F2): JRATE = 168; the FIPS 203 mode uses SHAKE256: JRATE = 136.
@@ -356,9 +386,11 @@ template <int K, int CLEN, bool HASH_CHECK, int JRATE = 168>
 __global__ void __launch_bounds__(WAVE, MLKEM_KECCAK_MINWAVES) k_hash_decaps(size_t n, const uint8_t* __restrict__ dk, const uint8_t* __restrict__ c,
                                                       const uint8_t* __restrict__ m_ws, uint8_t* __restrict__ Kp_ws,
                                                       uint8_t* __restrict__ r_ws, uint8_t* __restrict__ Kbar_ws,
-                                                      int32_t* __restrict__ status) {
+                                                      int32_t* __restrict__ status, size_t dk_stride) {
+    // dk_stride: bytes between the decapsulation keys of consecutive items (768k+96), or 0 for a shared-key batch
     __shared__ __attribute__((aligned(16))) uint2 stage[STAGE_QWORDS];
-    constexpr unsigned EK = 384 * K + 32, DK = 768 * K + 96;
+    constexpr unsigned EK = 384 * K + 32;
+    const size_t DK = dk_stride;
     const size_t item0 = (size_t)blockIdx.x * WAVE, item = item0 + lane_id();
     const size_t it = item < n ? item : n - 1;
     KeccakState s;

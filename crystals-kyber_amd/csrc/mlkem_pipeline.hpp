@@ -161,13 +161,21 @@ inline size_t min_sz(size_t a, size_t b) { return a < b ? a : b; }
 
 // SampleNTT for the k x k matrix + PRF rows of `n` items: the three-block main kernel, then the general kernel over
 // the leftover list (ml_kem.c:189-245, :496-515)
+// n_xof_items / n_prf_items: items whose matrix / PRF rows are produced (equal except for shared-key batches, where the
+// matrix is sampled once and the PRF rows per item)
+inline void launch_sample_split(stream_t st, const ParamSet& p, size_t n_xof_items, size_t n_prf_items, const uint8_t* rho,
+                                size_t rho_stride, int transpose, const uint8_t* r, int prf_per_item, int n_eta1, const Workspace& ws);
 inline void launch_sample(stream_t st, const ParamSet& p, size_t n, const uint8_t* rho, size_t rho_stride, int transpose,
                           const uint8_t* r, int prf_per_item, int n_eta1, const Workspace& ws) {
+    launch_sample_split(st, p, n, n, rho, rho_stride, transpose, r, prf_per_item, n_eta1, ws);
+}
+inline void launch_sample_split(stream_t st, const ParamSet& p, size_t n_xof_items, size_t n_prf_items, const uint8_t* rho,
+                                size_t rho_stride, int transpose, const uint8_t* r, int prf_per_item, int n_eta1, const Workspace& ws) {
     SampleArgs a{};
-    a.n_xof = n * (size_t)(p.k * p.k);
+    a.n_xof = n_xof_items * (size_t)(p.k * p.k);
     a.rho = rho; a.rho_stride = rho_stride; a.K = p.k; a.transpose = transpose; a.A = ws.A;
     a.xof_blocks = (unsigned)ceil_div(a.n_xof, WAVE);
-    a.n_prf = n * (size_t)prf_per_item;
+    a.n_prf = n_prf_items * (size_t)prf_per_item;
     a.r = r; a.per_item = prf_per_item; a.n_eta1 = n_eta1; a.eta1 = p.eta1; a.prf = ws.prf;
     a.prf_stride = p.eta1 == 3 ? 192 : 128;
     a.leftover = ws.leftover;
@@ -175,9 +183,11 @@ inline void launch_sample(stream_t st, const ParamSet& p, size_t n, const uint8_
     a.prf_rate = ws.fips ? 136 : 168;
     zero_u32(st, ws.leftover);
     const size_t grid = a.xof_blocks + ceil_div(a.n_prf, WAVE);
+    if (grid == 0) return;
     if (ws.ring == 128) launch("k_sample_main", k_sample_main<128>, grid, WAVE, st, a);
     else if (ws.ring == 32) launch("k_sample_main", k_sample_main<32>, grid, WAVE, st, a);
     else launch("k_sample_main", k_sample_main<64>, grid, WAVE, st, a);
+    if (a.n_xof == 0) return;
     // leftovers: expected 0.8 % of the sponges; the grid covers 1/16 of them and strides over the rest if ever needed
     SampleArgs t = a;
     t.list_mode = 1;
@@ -238,7 +248,7 @@ inline void encaps_run(stream_t st, const ParamSet& p, size_t n, const uint8_t* 
             launch("k_encrypt", k_encrypt<K, ETA1, DU, DV, false>, ceil_div(cn, ARITH_WAVES), WAVE * ARITH_WAVES,
                    pipe.arith_stream(buf), cn, eki, (size_t)p.ek_len, m + i0 * 32, (const uint16_t*)w.A, (const uint8_t*)w.prf,
                    c + i0 * p.c_len, (const uint8_t*)nullptr, (const uint8_t*)nullptr, (const uint8_t*)nullptr, (uint8_t*)nullptr,
-                   mod_status ? mod_status + i0 : (int32_t*)nullptr);
+                   mod_status ? mod_status + i0 : (int32_t*)nullptr, (size_t)(K * K * 256));
             pipe.end_chunk(buf);
         }
         pipe.join();
@@ -260,13 +270,13 @@ inline void decaps_run(stream_t st, const ParamSet& p, size_t n, const uint8_t* 
         int32_t* sth = (hash_check && status) ? status + h0 : (int32_t*)nullptr;
         const size_t hgrid = ceil_div(hn, WAVE);
         if (hash_check && !ws.fips)
-            launch("k_hash_decaps", k_hash_decaps<K, CLEN, true, 168>, hgrid, WAVE, st, hn, dkh, ch, (const uint8_t*)ws.m, ws.Kp, ws.r, ws.Kbar, sth);
+            launch("k_hash_decaps", k_hash_decaps<K, CLEN, true, 168>, hgrid, WAVE, st, hn, dkh, ch, (const uint8_t*)ws.m, ws.Kp, ws.r, ws.Kbar, sth, (size_t)p.dk_len);
         else if (!ws.fips)
-            launch("k_hash_decaps", k_hash_decaps<K, CLEN, false, 168>, hgrid, WAVE, st, hn, dkh, ch, (const uint8_t*)ws.m, ws.Kp, ws.r, ws.Kbar, sth);
+            launch("k_hash_decaps", k_hash_decaps<K, CLEN, false, 168>, hgrid, WAVE, st, hn, dkh, ch, (const uint8_t*)ws.m, ws.Kp, ws.r, ws.Kbar, sth, (size_t)p.dk_len);
         else if (hash_check)
-            launch("k_hash_decaps", k_hash_decaps<K, CLEN, true, 136>, hgrid, WAVE, st, hn, dkh, ch, (const uint8_t*)ws.m, ws.Kp, ws.r, ws.Kbar, sth);
+            launch("k_hash_decaps", k_hash_decaps<K, CLEN, true, 136>, hgrid, WAVE, st, hn, dkh, ch, (const uint8_t*)ws.m, ws.Kp, ws.r, ws.Kbar, sth, (size_t)p.dk_len);
         else
-            launch("k_hash_decaps", k_hash_decaps<K, CLEN, false, 136>, hgrid, WAVE, st, hn, dkh, ch, (const uint8_t*)ws.m, ws.Kp, ws.r, ws.Kbar, sth);
+            launch("k_hash_decaps", k_hash_decaps<K, CLEN, false, 136>, hgrid, WAVE, st, hn, dkh, ch, (const uint8_t*)ws.m, ws.Kp, ws.r, ws.Kbar, sth, (size_t)p.dk_len);
         ChunkPipe pipe(ws, st, ceil_div(hn, ws.cap));
         for (size_t c0 = 0; c0 < hn; c0 += ws.cap) {
             const size_t cn = min_sz(ws.cap, hn - c0), i0 = h0 + c0;
@@ -277,11 +287,85 @@ inline void decaps_run(stream_t st, const ParamSet& p, size_t n, const uint8_t* 
             launch("k_encrypt_cmp", k_encrypt<K, ETA1, DU, DV, true>, ceil_div(cn, ARITH_WAVES), WAVE * ARITH_WAVES,
                    pipe.arith_stream(buf), cn, dki + 384 * K, (size_t)p.dk_len, (const uint8_t*)(ws.m + c0 * 32), (const uint16_t*)w.A,
                    (const uint8_t*)w.prf, (uint8_t*)nullptr, c + i0 * p.c_len, (const uint8_t*)(ws.Kp + c0 * 32),
-                   (const uint8_t*)(ws.Kbar + c0 * 32), Kout + i0 * 32, (int32_t*)nullptr);
+                   (const uint8_t*)(ws.Kbar + c0 * 32), Kout + i0 * 32, (int32_t*)nullptr, (size_t)(K * K * 256));
             pipe.end_chunk(buf);
         }
         pipe.join();
     }
+}
+
+// ---- shared-key batches: ONE encapsulation key (encaps) or ONE decapsulation key (decaps) for all n items -----------
+// Same bytes as the per-item calls on replicated keys, but H(ek), the dk hash check and the k x k matrix (9 of the 44 /
+// 36 of the 51 Keccak-f per item at k = 3 ... plus H: 35 / 36) are computed once instead of n times.
+template <int K, int ETA1, int DU, int DV>
+inline void encaps_shared_run(stream_t st, const ParamSet& p, size_t n, const uint8_t* ek, const uint8_t* m, uint8_t* c, uint8_t* Kout,
+                              const Workspace& ws) {
+    const Workspace w = ws.view(0);
+    uint8_t* h = ws.rho;                                                          // 32 bytes, unused by Encaps otherwise
+    launch("k_hash_batch", k_hash_batch<0>, (size_t)1, WAVE, st, (size_t)1, ek, (unsigned)p.ek_len, (size_t)p.ek_len, h);
+    launch_sample_split(st, p, 1, 0, ek + 384 * K, p.ek_len, /*transpose=*/1, nullptr, 0, 0, w);   // A^T once
+    for (size_t h0 = 0; h0 < n; h0 += ws.hcap) {
+        const size_t hn = min_sz(ws.hcap, n - h0);
+        launch("k_hash_g_shared", k_hash_g_shared, ceil_div(hn, WAVE), WAVE, st, hn, m + h0 * 32, (const uint8_t*)h, Kout + h0 * 32, ws.r);
+        for (size_t c0 = 0; c0 < hn; c0 += ws.cap) {
+            const size_t cn = min_sz(ws.cap, hn - c0), i0 = h0 + c0;
+            launch_sample_split(st, p, 0, cn, nullptr, 0, 1, ws.r + c0 * 32, 2 * K + 1, K, w);      // PRF rows per item
+            launch("k_encrypt", k_encrypt<K, ETA1, DU, DV, false>, ceil_div(cn, ARITH_WAVES), WAVE * ARITH_WAVES, st, cn, ek, (size_t)0,
+                   m + i0 * 32, (const uint16_t*)w.A, (const uint8_t*)w.prf, c + i0 * p.c_len, (const uint8_t*)nullptr,
+                   (const uint8_t*)nullptr, (const uint8_t*)nullptr, (uint8_t*)nullptr, (int32_t*)nullptr, (size_t)0);
+        }
+    }
+}
+template <int K, int ETA1, int DU, int DV>
+inline void decaps_shared_run(stream_t st, const ParamSet& p, size_t n, const uint8_t* dk, const uint8_t* c, uint8_t* Kout,
+                              int32_t* status, const Workspace& ws) {
+    constexpr int CLEN = 32 * (DU * K + DV);
+    const Workspace w = ws.view(0);
+    if (status) {   // KEM_Decaps' hash check, once
+        launch("k_hash_batch", k_hash_batch<0>, (size_t)1, WAVE, st, (size_t)1, dk + 384 * K, (unsigned)p.ek_len, (size_t)p.dk_len, ws.rho);
+        launch("k_status_fill", k_status_fill, min_sz(ceil_div(n, 256), 1024), 256u, st, n, (const uint8_t*)ws.rho, dk + 768 * K + 32, status);
+    }
+    launch_sample_split(st, p, 1, 0, dk + 768 * K, p.dk_len, /*transpose=*/1, nullptr, 0, 0, w);   // A^T once (rho sits in dk.ek)
+    for (size_t h0 = 0; h0 < n; h0 += ws.hcap) {
+        const size_t hn = min_sz(ws.hcap, n - h0);
+        const uint8_t* ch = c + h0 * p.c_len;
+        launch("k_decrypt", k_decrypt<K, DU, DV>, ceil_div(hn, ARITH_WAVES), WAVE * ARITH_WAVES, st, hn, dk, (size_t)0, ch, ws.m);
+        const size_t hgrid = ceil_div(hn, WAVE);
+        if (!ws.fips)
+            launch("k_hash_decaps", k_hash_decaps<K, CLEN, false, 168>, hgrid, WAVE, st, hn, dk, ch, (const uint8_t*)ws.m, ws.Kp, ws.r, ws.Kbar, (int32_t*)nullptr, (size_t)0);
+        else
+            launch("k_hash_decaps", k_hash_decaps<K, CLEN, false, 136>, hgrid, WAVE, st, hn, dk, ch, (const uint8_t*)ws.m, ws.Kp, ws.r, ws.Kbar, (int32_t*)nullptr, (size_t)0);
+        for (size_t c0 = 0; c0 < hn; c0 += ws.cap) {
+            const size_t cn = min_sz(ws.cap, hn - c0), i0 = h0 + c0;
+            launch_sample_split(st, p, 0, cn, nullptr, 0, 1, ws.r + c0 * 32, 2 * K + 1, K, w);
+            launch("k_encrypt_cmp", k_encrypt<K, ETA1, DU, DV, true>, ceil_div(cn, ARITH_WAVES), WAVE * ARITH_WAVES, st, cn, dk + 384 * K,
+                   (size_t)0, (const uint8_t*)(ws.m + c0 * 32), (const uint16_t*)w.A, (const uint8_t*)w.prf, (uint8_t*)nullptr, c + i0 * p.c_len,
+                   (const uint8_t*)(ws.Kp + c0 * 32), (const uint8_t*)(ws.Kbar + c0 * 32), Kout + i0 * 32, (int32_t*)nullptr, (size_t)0);
+        }
+    }
+}
+inline int encaps_shared_dispatch(stream_t st, int set, size_t n, const uint8_t* ek, const uint8_t* m, uint8_t* c, uint8_t* K, const Workspace& ws) {
+    ParamSet p;
+    if (!param_set(set, p)) return -1;
+    if (n == 0) return 0;
+    switch (set) {
+    case 512: encaps_shared_run<2, 3, 10, 4>(st, p, n, ek, m, c, K, ws); break;
+    case 768: encaps_shared_run<3, 2, 10, 4>(st, p, n, ek, m, c, K, ws); break;
+    default: encaps_shared_run<4, 2, 11, 5>(st, p, n, ek, m, c, K, ws); break;
+    }
+    return 0;
+}
+inline int decaps_shared_dispatch(stream_t st, int set, size_t n, const uint8_t* dk, const uint8_t* c, uint8_t* K, int32_t* status,
+                                  const Workspace& ws) {
+    ParamSet p;
+    if (!param_set(set, p)) return -1;
+    if (n == 0) return 0;
+    switch (set) {
+    case 512: decaps_shared_run<2, 3, 10, 4>(st, p, n, dk, c, K, status, ws); break;
+    case 768: decaps_shared_run<3, 2, 10, 4>(st, p, n, dk, c, K, status, ws); break;
+    default: decaps_shared_run<4, 2, 11, 5>(st, p, n, dk, c, K, status, ws); break;
+    }
+    return 0;
 }
 
 inline int keygen_dispatch(stream_t st, int set, size_t n, const uint8_t* d, const uint8_t* z, uint8_t* ek, uint8_t* dk,

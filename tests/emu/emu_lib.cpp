@@ -60,6 +60,18 @@ int emu_decaps(int set, size_t n, const uint8_t* dk, const uint8_t* c, uint8_t* 
     free_ws(ws);
     return rc;
 }
+int emu_encaps_shared(int set, size_t n, const uint8_t* ek, const uint8_t* m, uint8_t* c, uint8_t* K) {
+    Workspace ws = make_ws(n);
+    int rc = encaps_shared_dispatch(nullptr, set, n, ek, m, c, K, ws);
+    free_ws(ws);
+    return rc;
+}
+int emu_decaps_shared(int set, size_t n, const uint8_t* dk, const uint8_t* c, uint8_t* K, int32_t* status) {
+    Workspace ws = make_ws(n);
+    int rc = decaps_shared_dispatch(nullptr, set, n, dk, c, K, status, ws);
+    free_ws(ws);
+    return rc;
+}
 int emu_pke_keygen(int set, size_t n, const uint8_t* d, uint8_t* ek, uint8_t* dk_pke) {
     Workspace ws = make_ws(n);
     int rc = pke_keygen_dispatch(nullptr, set, n, d, ek, dk_pke, ws);

@@ -141,6 +141,34 @@ def test_emu_codec_primitives(emu, oracle, golden_npz, d):
 
 
 @pytest.mark.parametrize("pset", (512, 768, 1024))
+def test_emu_shared_key_batches(emu, oracle, pset):
+    """One key for the whole batch: same bytes as the per-item path on the replicated key (oracle), incl. implicit
+    rejection and the once-per-call dk hash check; chunk loops crossed (cap 3, hcap 7, 17 items)."""
+    emu.emu_config(C.c_size_t(3), C.c_size_t(7), 64)
+    try:
+        ekl, dkl, cl = SIZES[pset]
+        n = 17
+        d, z, m = seeds("sh-d", 1, pset), seeds("sh-z", 1, pset), seeds("sh-m", n, pset)
+        ek1, dk1 = oracle.keygen(pset, d, z)
+        c, K = np.zeros((n, cl), np.uint8), np.zeros((n, 32), np.uint8)
+        assert emu.emu_encaps_shared(pset, C.c_size_t(n), p8(ek1), p8(m), p8(c), p8(K)) == 0
+        c_o, K_o = oracle.encaps(pset, np.repeat(ek1, n, axis=0), m)
+        assert (c == c_o).all() and (K == K_o).all()
+        cb = c.copy()
+        cb[[0, 5, 16], [1, cl - 1, 77]] ^= 8
+        Kd, st = np.zeros((n, 32), np.uint8), np.ones(n, np.int32)
+        assert emu.emu_decaps_shared(pset, C.c_size_t(n), p8(dk1), p8(cb), p8(Kd), st.ctypes.data_as(C.POINTER(C.c_int32))) == 0
+        Kd_o, st_o = oracle.decaps(pset, np.repeat(dk1, n, axis=0), cb)
+        assert (st == 0).all() and (st_o == 0).all() and (Kd == Kd_o).all()
+        dkb = dk1.copy()
+        dkb[0, dkl - 50] ^= 1                              # stored H(ek) corrupted: every item reports -5
+        assert emu.emu_decaps_shared(pset, C.c_size_t(n), p8(dkb), p8(cb), p8(Kd), st.ctypes.data_as(C.POINTER(C.c_int32))) == 0
+        assert (st == -5).all()
+    finally:
+        emu.emu_config(C.c_size_t(0), C.c_size_t(0), 64)
+
+
+@pytest.mark.parametrize("pset", (512, 768, 1024))
 def test_emu_k_pke_alone(emu, oracle, pset):
     """PKE_KeyGen / PKE_Encrypt (caller's randomness) / PKE_Decrypt as stand-alone entry points."""
     ekl, dkl, cl = SIZES[pset]

@@ -264,6 +264,37 @@ def test_random_shapes_vs_oracle(pkg, torch, oracle):
         e.close()
 
 
+@pytest.mark.parametrize("pset", SETS)
+def test_shared_key_batches(pkg, torch, oracle, pset):
+    """One ek / dk for the whole batch: bytes equal to the per-item path on the replicated key (oracle on a sample, the
+    per-item GPU path on everything), implicit rejection, once-per-call hash check, chunk boundaries crossed."""
+    ekl, dkl, cl = SIZES[pset]
+    e = pkg.MLKEM(pset, device=0, chunk_items=700)
+    n = 3000
+    d, z, m = seeds("shg-d", 1, pset), seeds("shg-z", 1, pset), seeds("shg-m", n, pset)
+    ek1, dk1 = e.keygen(dev(torch, d), dev(torch, z))
+    c, K = e.encaps_shared(ek1, dev(torch, m))
+    c_r, K_r = e.encaps(ek1.expand(n, ekl).contiguous(), dev(torch, m))
+    assert torch.equal(c, c_r) and torch.equal(K, K_r)
+    idx = [0, 1, 63, 64, 699, 700, 2999]
+    c_o, K_o = oracle.encaps(pset, np.repeat(host(ek1), len(idx), axis=0), m[idx])
+    assert (host(c)[idx] == c_o).all() and (host(K)[idx] == K_o).all()
+    cb = c.clone()
+    bad = torch.arange(0, n, 37, device="cuda")
+    cb[bad, (bad * 7) % cl] ^= 0x20
+    Kd, st = e.decaps_shared(dk1, cb)
+    Kd_r, st_r = e.decaps(dk1.expand(n, dkl).contiguous(), cb)
+    assert torch.equal(Kd, Kd_r) and torch.equal(st, st_r) and int(st.abs().max()) == 0
+    same = (Kd == K).all(dim=1)
+    assert not bool(same[bad].any()) and int(same.sum()) == n - bad.numel()
+    dkb = dk1.clone()
+    dkb[0, dkl - 40] ^= 2
+    Kd2, st2 = e.decaps_shared(dkb, cb)
+    Kd2_r, st2_r = e.decaps(dkb.expand(n, dkl).contiguous(), cb)
+    assert bool((st2 == -5).all()) and torch.equal(st2, st2_r) and torch.equal(Kd2, Kd2_r)
+    e.close()
+
+
 def test_empty_batches(engines, torch):
     e = engines[768]
     u8 = torch.uint8
