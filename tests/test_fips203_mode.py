@@ -114,6 +114,15 @@ def test_gpu_fips_mode(fips_oracle, pset):
     # item 0 against the independent Python restatement directly
     ek_p, dk_p = F.keygen(pset, bytes(d[0]), bytes(z[0]))
     assert bytes(ek.cpu().numpy()[0]) == ek_p and bytes(dk.cpu().numpy()[0]) == dk_p
+    # shared-key batches in FIPS mode (PRF and J on SHAKE256 there too): key 0 for everything
+    c_s, K_s = e.encaps_shared(ek[0], dev(m))
+    c_so, K_so = fips_oracle.encaps(pset, np.repeat(ek_o[:1], n, axis=0), m)
+    assert (c_s.cpu().numpy() == c_so).all() and (K_s.cpu().numpy() == K_so).all()
+    cs = c_so.copy()
+    cs[::5, 3] ^= 1
+    Kd_s, st_s = e.decaps_shared(dk[0], dev(cs))
+    Kd_so, st_so = fips_oracle.decaps(pset, np.repeat(dk_o[:1], n, axis=0), cs)
+    assert (Kd_s.cpu().numpy() == Kd_so).all() and (st_s.cpu().numpy() == st_so).all()
     e.close()
     # the default (reference-compatible) mode reports status 0 for the same bad key (F3)
     r = pkg.MLKEM(pset, device=0)
