@@ -219,7 +219,7 @@ union bit* h2b(const union hex* H, unsigned int m, unsigned int n) {   /* sha3.c
 
 union hex* b2h(const union bit* S, unsigned int n) {   /* sha3.c:367-396 */
     unsigned int m = (n + 7) / 8;
-    union hex* H = (union hex*)calloc(2 * m ? 2 * m : 1, sizeof(union hex));
+    union hex* H = (union hex*)calloc(m ? 2 * (size_t)m : 1, sizeof(union hex));
     if (!H) return NULL;
     for (unsigned int i = 0; i < m; i++) {
         unsigned int byte = 0;
@@ -265,7 +265,7 @@ union hex* sha3_h(const union hex* hstr, unsigned int m, unsigned int d, unsigne
 }
 
 unsigned char* sha3_s(const char* cstr, unsigned int m, unsigned int d, unsigned int c, union bit sfx[4]) {   /* sha3.c:465-494 */
-    union hex* H = (union hex*)calloc(2 * m ? 2 * m : 1, sizeof(union hex));
+    union hex* H = (union hex*)calloc(m ? 2 * (size_t)m : 1, sizeof(union hex));
     if (!H) return NULL;
     for (unsigned int i = 0; i < m; i++) {
         H[2 * i].d = ((unsigned char)cstr[i] >> 4) & 15u;
