@@ -255,15 +255,17 @@ def run_ntt(args, rank, world, device):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 5; 40 for the sub-millisecond NTT workload)")
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=None,
+                    help="timed steps (default 20: ~0.4 s, long enough for the power-capped clock to settle; 200 for the "
+                         "sub-millisecond NTT workload)")
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="kem768", choices=("kem768", "kem1024", "kem512", "ntt", "kem768_shared"))
     ap.add_argument("--batch", type=int, default=1 << 20, help="items per GPU per step (BASELINE: 2^20)")
     ap.add_argument("--chunk", type=int, default=0, help="engine chunk size in items (0 = library default)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     args = ap.parse_args()
     if args.steps is None:
-        args.steps = 40 if args.workload == "ntt" else 5
+        args.steps = 200 if args.workload == "ntt" else 20
 
     rank, world, local = dist_setup(args.gpus)
     if not torch.cuda.is_available():
