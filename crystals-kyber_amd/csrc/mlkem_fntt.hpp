@@ -96,6 +96,18 @@ __device__ __forceinline__ void ct_bfly_f(float& a, float& b, Tw zeta) {
     b = a - t;
     a = a + t;
 }
+// the same with a COMPILE-TIME twiddle (the two outermost layers and the final scaling): zeta and zeta/q are literals, so
+// the 3-FMA product costs no registers and is one instruction shorter than mul + Barrett
+__device__ __forceinline__ void ct_bfly_c(float& a, float& b, Tw zeta) {
+    const float t = fmulmod_shoup(zeta, b);
+    b = a - t;
+    a = a + t;
+}
+__device__ __forceinline__ void gs_bfly_c(float& a, float& b, Tw zeta) {
+    const float t = a;
+    a = t + b;
+    b = fmulmod_shoup(zeta, b - t);
+}
 // Gentleman-Sande (ml_kem.c:359-373): a' = a + b, b' = zeta (b - a)
 __device__ __forceinline__ void gs_bfly_f(float& a, float& b, Tw zeta) {
     const float t = a;
@@ -136,8 +148,8 @@ __device__ __forceinline__ void wave_ntt_f(float (&x)[4], float* xch, const NttT
 }
 __device__ __forceinline__ void wave_ntt_la_f(float (&x)[4], float* xch, const NttTwiddlesF& tw) {
     const int l = lane_id();
-    ct_bfly_f(x[0], x[2], FZ1); ct_bfly_f(x[1], x[3], FZ1);          // len 128 : <= 3328 + 1665
-    ct_bfly_f(x[0], x[1], FZ2); ct_bfly_f(x[2], x[3], FZ3);          // len 64  : <= 3328 + 2*1665
+    ct_bfly_c(x[0], x[2], FZ1); ct_bfly_c(x[1], x[3], FZ1);          // len 128 : <= 3328 + 1665
+    ct_bfly_c(x[0], x[1], FZ2); ct_bfly_c(x[2], x[3], FZ3);          // len 64  : <= 3328 + 2*1665
     wave_lds_fence();
     MLKEM_FX_WRITE(idx_LA)
     wave_lds_fence();
@@ -185,10 +197,10 @@ __device__ __forceinline__ void wave_intt_f(float (&x)[4], float* xch, const Ntt
     MLKEM_FX_WRITE(idx_LB)
     wave_lds_fence();
     MLKEM_FX_READ(idx_LA)
-    gs_bfly_f(x[0], x[1], FZ3); gs_bfly_f(x[2], x[3], FZ2);          // len 64
-    gs_bfly_f(x[0], x[2], FZ1); gs_bfly_f(x[1], x[3], FZ1);          // len 128 : <= 6660
+    gs_bfly_c(x[0], x[1], FZ3); gs_bfly_c(x[2], x[3], FZ2);          // len 64
+    gs_bfly_c(x[0], x[2], FZ1); gs_bfly_c(x[1], x[3], FZ1);          // len 128 : <= 6660
 #pragma unroll
-    for (int m = 0; m < 4; m++) x[m] = fmulmod(F_INV128, x[m]);       // x 128^-1 : |-26 * 6660| << 2^24
+    for (int m = 0; m < 4; m++) x[m] = fmulmod_shoup(F_INV128, x[m]);  // x 128^-1 : |-26 * 6660| << 2^24
     wave_lds_fence();
     MLKEM_FX_WRITE(idx_LA)
     wave_lds_fence();
