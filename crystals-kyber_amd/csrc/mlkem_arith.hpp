@@ -101,7 +101,7 @@ template <int D, bool COMPARE>
 __device__ __forceinline__ uint32_t emit_compressed(uint32_t* cbuf, const float (&x)[4], uint8_t* out, const CodecRegs<D>& ref) {
     unsigned v[4];
 #pragma unroll
-    for (int m = 0; m < 4; m++) v[m] = compress_d<D>((unsigned)fcanon(x[m]));
+    for (int m = 0; m < 4; m++) v[m] = compress_f<D>(x[m]);
     codec_zero<D>(cbuf);
     wave_lds_fence();
     codec_encode<D>(cbuf, v);
@@ -298,7 +298,7 @@ k_decrypt(size_t n, const uint8_t* __restrict__ dk, size_t dk_stride, const uint
     decode_regs<DV, true>(L.cbuf, cv, v);
     unsigned bits = 0;
 #pragma unroll
-    for (int m = 0; m < 4; m++) bits |= compress_d<1>((unsigned)fcanon(v[m] - acc[m])) << m;   // ml_kem.c:1003-1011
+    for (int m = 0; m < 4; m++) bits |= compress_f<1>(v[m] - acc[m]) << m;   // ml_kem.c:1003-1011
     // ByteEncode_1: lane l owns nibble l of the 32-byte message
     const unsigned other = (unsigned)__shfl_xor((int)bits, 1);
     if ((l & 1) == 0) m_out[item * 32 + (l >> 1)] = (uint8_t)(bits | (other << 4));

@@ -63,6 +63,25 @@ __device__ __forceinline__ int fcanon(float x) {
     return (int)r;
 }
 
+// Compress_d (ml_kem.c:83-97) of ANY representative x (integer, |x| <= 4095) without canonicalising it first:
+// round(2^d x / q) mod 2^d is invariant under x -> x + q, and q is odd, so there are no ties.
+//   t  = 2^d x                         exact (|t| < 2^23.1)
+//   k0 = rint(t fl(1/q))               off by one only when frac(t/q) is within 1.2e-4 of 1/2
+//   r  = t - k0 q                      exact; |r| <= 1665, and |r| = 1665 exactly in the off-by-one case
+//   k  = k0 + rint(r fl(1/q))          rint(+-0.50015) = +-1 repairs it; otherwise the term is 0
+// Seven full-rate fp32 instructions + one conversion + one AND, against canonicalise (5) + convert + shift/add + 32-bit
+// mul_hi + shift + AND (five of them slow-class) in the integer form.  Verified exhaustively (tests/emu: every
+// |x| <= 4095, d in {1, 4, 5, 10, 11}, against the integer form on the canonical representative).
+template <int D>
+__device__ __forceinline__ unsigned compress_f(float x) {
+    static_assert(D >= 1 && D <= 11, "d");
+    const float t = x * (float)(1 << D);
+    const float k0 = __builtin_fmaf(t, F_INVQ, F_MAGIC) - F_MAGIC;
+    const float r = __builtin_fmaf(k0, -F_Q, t);
+    const float k = k0 + (__builtin_fmaf(r, F_INVQ, F_MAGIC) - F_MAGIC);
+    return (unsigned)(int)k & ((1u << D) - 1u);
+}
+
 struct ZetaTableF {
     Tw z[128];
     constexpr ZetaTableF() : z{} {

@@ -39,6 +39,18 @@ static void free_ws(Workspace& ws) {
     free(ws.r); free(ws.rho); free(ws.m); free(ws.Kp); free(ws.Kbar);
 }
 
+// Exhaustive check of the fp32 Compress_d (mlkem_fntt.hpp: compress_f) for every integer |x| <= 4095 and every d ML-KEM
+// uses, against the integer form on the canonical representative.  Returns the number of mismatches.
+template <int D>
+static long compress_f_mismatches() {
+    long bad = 0;
+    for (int x = -4095; x <= 4095; x++) {
+        const unsigned canon = (unsigned)(((x % KQ) + KQ) % KQ);
+        if (compress_f<D>((float)x) != compress_d<D>(canon)) bad++;
+    }
+    return bad;
+}
+
 extern "C" {
 void emu_config(size_t cap, size_t hcap, int ring) { g_cap = cap; g_hcap = hcap; g_ring = (ring == 128 || ring == 32) ? ring : 64; }
 void emu_conformance(int fips) { g_fips = fips != 0; }
@@ -135,5 +147,9 @@ long emu_fmulmod_exhaustive(void) {
         }
     }
     return bad;
+}
+long emu_compress_f_exhaustive(void) {
+    return compress_f_mismatches<1>() + compress_f_mismatches<4>() + compress_f_mismatches<5>() + compress_f_mismatches<10>() +
+           compress_f_mismatches<11>();
 }
 }

@@ -48,6 +48,12 @@ def test_emu_fp32_twiddle_product_exhaustive(emu):
     assert emu.emu_fmulmod_exhaustive() == 0
 
 
+def test_emu_fp32_compress_exhaustive(emu):
+    """Compress_d on the fp32 pipe, every |x| <= 4095 (any representative) x d in {1,4,5,10,11}, against the integer form."""
+    emu.emu_compress_f_exhaustive.restype = C.c_long
+    assert emu.emu_compress_f_exhaustive() == 0
+
+
 def test_emu_sampling(emu, oracle, golden_npz):
     s = golden_npz["g2_in"].copy()
     out = np.zeros((s.shape[0], 256), np.uint16)
