@@ -53,9 +53,19 @@ __device__ __forceinline__ uint32_t cbd_load(const uint8_t* prf) {
 template <int ETA>
 __device__ __forceinline__ void cbd_eval_f(uint32_t t, float (&x)[4]) {
     if constexpr (ETA == 2) {
-        const uint32_t d = (t & 0x5555u) + ((t >> 1) & 0x5555u);   // pairwise bit sums
-#pragma unroll
-        for (int m = 0; m < 4; m++) x[m] = (float)((int)((d >> (4 * m)) & 3u) - (int)((d >> (4 * m + 2)) & 3u));
+        // coefficient m = (a0 + a1) - (b0 + b1) of nibble m = popcount(nibble ^ 0b1100) - 2.  The four nibbles are spread
+        // to the four bytes of one register (order n0, n2, n1, n3), counted in parallel, and converted with
+        // v_cvt_f32_ubyteN: 19 instructions for the 4 coefficients, 7 of them slow-class (the per-coefficient bit-field
+        // form took 27, most of them slow-class).
+        uint32_t u = ((t | (t << 12)) & 0x0F0F0F0Fu) ^ 0x0C0C0C0Cu;
+        u = (u & 0x05050505u) + ((u >> 1) & 0x05050505u);
+        u = (u & 0x03030303u) + ((u >> 2) & 0x03030303u);
+        float c0 = (float)(u & 0xFFu), c2 = (float)((u >> 8) & 0xFFu), c1 = (float)((u >> 16) & 0xFFu), c3 = (float)(u >> 24);
+#ifndef MLKEM_EMU   // keep the byte -> float conversions as they are (v_cvt_f32_ubyteN): folding the "- 2" into an
+                    // integer subtract per byte costs a second slow-class instruction per coefficient
+        asm volatile("" : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3));
+#endif
+        x[0] = c0 - 2.0f; x[1] = c1 - 2.0f; x[2] = c2 - 2.0f; x[3] = c3 - 2.0f;
     } else {
         const uint32_t d = (t & 0x249249u) + ((t >> 1) & 0x249249u) + ((t >> 2) & 0x249249u);   // 3-bit group sums
 #pragma unroll

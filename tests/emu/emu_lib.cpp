@@ -152,4 +152,19 @@ long emu_compress_f_exhaustive(void) {
     return compress_f_mismatches<1>() + compress_f_mismatches<4>() + compress_f_mismatches<5>() + compress_f_mismatches<10>() +
            compress_f_mismatches<11>();
 }
+// cbd_eval_f<2> (mlkem_arith.hpp) over every 16-bit input against the definition (ml_kem.c:253-275): per nibble
+// (a0 + a1) - (b0 + b1).  Returns the number of mismatches.
+long emu_cbd2_exhaustive(void) {
+    long bad = 0;
+    for (uint32_t t = 0; t < 65536; t++) {
+        float x[4];
+        cbd_eval_f<2>(t, x);
+        for (int m = 0; m < 4; m++) {
+            const uint32_t n = (t >> (4 * m)) & 15u;
+            const int want = (int)((n & 1) + ((n >> 1) & 1)) - (int)(((n >> 2) & 1) + ((n >> 3) & 1));
+            if (x[m] != (float)want) bad++;
+        }
+    }
+    return bad;
+}
 }

@@ -54,6 +54,12 @@ def test_emu_fp32_compress_exhaustive(emu):
     assert emu.emu_compress_f_exhaustive() == 0
 
 
+def test_emu_cbd2_exhaustive(emu):
+    """The byte-parallel eta = 2 CBD evaluation over all 65536 inputs of a lane against the definition."""
+    emu.emu_cbd2_exhaustive.restype = C.c_long
+    assert emu.emu_cbd2_exhaustive() == 0
+
+
 def test_emu_sampling(emu, oracle, golden_npz):
     s = golden_npz["g2_in"].copy()
     out = np.zeros((s.shape[0], 256), np.uint16)
