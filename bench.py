@@ -2,14 +2,19 @@
 """bench.py — BASELINE.json's headline metric on MI355X:
 ML-KEM-768 encaps+decaps pairs per second at batch 2^20 (BASELINE configs[2]), inputs resident in HBM.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload kem768|kem1024|kem512|ntt]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload kem768|kem1024|kem512|ntt] [--rehearse]
 
 One "step" = one pass of the hot path over one batch: Encaps_internal over 2^20 (ek, m) followed by KEM_Decaps
 (hash check included, as the reference's public API does) over the 2^20 (dk, c) it produced.  Keys come from the
 engine's own batch KeyGen on seeds d_i, z_i, m_i = SHAKE128(label || LE64(i) || LE64(0xC0FFEE))[:32] (untimed).
 N > 1: one process per GPU (torchrun), every rank runs the same per-GPU batch on its own item range (weak
 scaling, no collective in the data path); the timed region is bracketed by barrier + synchronize and the MAX
-over ranks is used.  Rank 0 prints ONE JSON line.
+over ranks is used.  Rank 0 prints ONE JSON line.  When the node has fewer GPUs than ranks (or with --rehearse) the
+ranks share the visible GPU(s) and the barrier runs over gloo instead of RCCL: a rehearsal of the N-rank path on a
+one-GPU box (the line says so in config.parallelism; its value is not a scaling result).
+
+At N = 1 the line also carries `also`: BASELINE configs[1] (NTT-only) and configs[3] (ML-KEM-1024 KeyGen+Encaps+Decaps)
+measured in the same process right after the headline, each with value / ms_per_step / correct / roofline.
 
 Extra objects on the line:
   roofline      whole-pass algorithmic bytes (5856 B per pair) / pass time vs the 8 TB/s HBM peak, the
@@ -58,15 +63,28 @@ def device_seeds(label, start, n, device):
     return out
 
 
-def dist_setup(n_gpus):
+SHARED_GPU = False   # set by dist_setup: ranks share a GPU (rehearsal), the barrier runs over gloo
+
+
+def dist_setup(n_gpus, rehearse=False):
+    """Returns (rank, world, device index).  One rank per GPU over RCCL when the node has a GPU per rank; otherwise (or
+    with rehearse=True) the ranks are dealt round-robin over the visible GPUs and synchronise over gloo."""
+    global SHARED_GPU
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+        ndev = torch.cuda.device_count()   # counting devices does not initialise the GPU
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+        SHARED_GPU = bool(rehearse) or (0 < ndev < local_world)
+        if SHARED_GPU:
+            local = local % max(ndev, 1)
+            dist.init_process_group(backend="gloo")
+        else:
+            torch.cuda.set_device(local)
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
     elif n_gpus > 1:
         raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one process per GPU)")
     return rank, world, local
@@ -82,7 +100,8 @@ def max_over_ranks(x, world, device):
     if world == 1:
         return x
     import torch.distributed as dist
-    t = torch.tensor([x], dtype=torch.float64, device=device)
+    on_cpu = SHARED_GPU or dist.get_backend() == "gloo"
+    t = torch.tensor([x], dtype=torch.float64, device="cpu" if on_cpu else device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
@@ -91,7 +110,7 @@ def cpu_baseline(pset, ek, dk, m, c_gpu, K_gpu, want_seconds=20.0):
     """Time the reference (or the port) on the host cores over a bounded sample of the SAME items."""
     from concurrent.futures import ThreadPoolExecutor
     from oracle import loader
-    cores = max(1, min(len(os.sched_getaffinity(0)), 16))
+    cores = max(1, len(os.sched_getaffinity(0)))   # every host core this process may run on; the count is reported
     n_all = m.shape[0]
     use_ref = loader.Ref.available()
     if use_ref:   # calibrate on one pair (30-80 ms per pair per core at -O2), then size for ~want_seconds of CPU work
@@ -252,56 +271,48 @@ def run_ntt(args, rank, world, device):
     return elapsed, ok, extra
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=None,
-                    help="timed steps (default 20: ~0.4 s, long enough for the power-capped clock to settle; 200 for the "
-                         "sub-millisecond NTT workload)")
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="kem768", choices=("kem768", "kem1024", "kem512", "ntt", "kem768_shared"))
-    ap.add_argument("--batch", type=int, default=1 << 20, help="items per GPU per step (BASELINE: 2^20)")
-    ap.add_argument("--chunk", type=int, default=0, help="engine chunk size in items (0 = library default)")
-    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    args = ap.parse_args()
-    if args.steps is None:
-        args.steps = 200 if args.workload == "ntt" else 20
+def source_id():
+    """sha256 over the kernel / C-ABI sources: ties a committed PMC traffic file to the build it was measured on (there is
+    no .git on the GPU box, so the commit hash itself cannot be checked there)."""
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "crystals-kyber_amd", "csrc")
+    for f in sorted(x for x in os.listdir(csrc) if x.endswith((".hpp", ".hip", ".c"))) + ["../../include/mlkem_batch.h"]:
+        with open(os.path.join(csrc, f), "rb") as fh:
+            h.update(f.encode() + b"\0" + fh.read())
+    return h.hexdigest()[:16]
 
-    rank, world, local = dist_setup(args.gpus)
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a HIP device: the engine has no CPU fallback")
-    device = torch.device("cuda", local)
-    torch.cuda.set_device(device)
 
-    if args.workload == "ntt":
-        elapsed, ok, extra = run_ntt(args, rank, world, device)
-        metric, unit = "batched forward+inverse NTT polynomials/sec at batch 2^20", "polys/s"
-        wl = "configs[1]: batched forward+inverse NTT only, %d polynomials per GPU" % args.batch
-        dtype = "f32 (exact integer arithmetic < 2^24), u16 I/O"
-    else:
-        pset = {"kem768": 768, "kem1024": 1024, "kem512": 512, "kem768_shared": 768}[args.workload]
-        elapsed, ok, extra = run_kem(args, pset, rank, world, device)
-        if args.workload == "kem768_shared":
-            metric, unit = "ML-KEM-768 encaps+decaps/sec at batch 2^20, ONE key pair for the whole batch", "pairs/s"
-            wl = "extra (not a BASELINE config): ML-KEM-768 Encaps+Decaps of %d items to / under one key (mlkem_*_shared_dev)" % args.batch
-        elif args.workload == "kem768":
-            metric, unit = "ML-KEM-768 encaps+decaps/sec at batch 2^20; achieved HBM GB/s vs peak", "pairs/s"
-            wl = "configs[2]: ML-KEM-768 full Encaps+Decaps (KEM_Decaps incl. dk hash check), batch %d per GPU, keys from batch KeyGen (untimed)" % args.batch
-        else:
-            metric, unit = "ML-KEM-%d keygen+encaps+decaps/sec at batch 2^20" % pset, "triples/s"
-            wl = "%sML-KEM-%d KeyGen+Encaps+Decaps, batch %d per GPU" % ("configs[3]: " if pset == 1024 else "", pset, args.batch)
-        dtype = "u32+f32 (64-bit Keccak lanes as 2 x u32; mod-3329 arithmetic exact on integers < 2^24 in the fp32 pipe; u8/u16 I/O)"
+WORKLOAD_META = {
+    "ntt": ("batched forward+inverse NTT polynomials/sec at batch 2^20", "polys/s",
+            "configs[1]: batched forward+inverse NTT only, %d polynomials per GPU",
+            "f32 (exact integer arithmetic < 2^24), u16 I/O"),
+    "kem768": ("ML-KEM-768 encaps+decaps/sec at batch 2^20; achieved HBM GB/s vs peak", "pairs/s",
+               "configs[2]: ML-KEM-768 full Encaps+Decaps (KEM_Decaps incl. dk hash check), batch %d per GPU, keys from batch KeyGen (untimed)", None),
+    "kem1024": ("ML-KEM-1024 keygen+encaps+decaps/sec at batch 2^20", "triples/s", "configs[3]: ML-KEM-1024 KeyGen+Encaps+Decaps, batch %d per GPU", None),
+    "kem512": ("ML-KEM-512 keygen+encaps+decaps/sec at batch 2^20", "triples/s", "ML-KEM-512 KeyGen+Encaps+Decaps, batch %d per GPU", None),
+    "kem768_shared": ("ML-KEM-768 encaps+decaps/sec at batch 2^20, ONE key pair for the whole batch", "pairs/s",
+                      "extra (not a BASELINE config): ML-KEM-768 Encaps+Decaps of %d items to / under one key (mlkem_*_shared_dev)", None),
+}
+KEM_DTYPE = "u32+f32 (64-bit Keccak lanes as 2 x u32; mod-3329 arithmetic exact on integers < 2^24 in the fp32 pipe; u8/u16 I/O)"
 
-    if rank != 0:
-        return
+
+def run_workload(workload, args, rank, world, device):
+    if workload == "ntt":
+        return run_ntt(args, rank, world, device)
+    pset = {"kem768": 768, "kem1024": 1024, "kem512": 512, "kem768_shared": 768}[workload]
+    return run_kem(args, pset, rank, world, device)
+
+
+def entry(workload, args, elapsed, ok, extra, world):
+    """value / ms_per_step / roofline / kernels of one measured workload (the headline and each `also` member)."""
     units = args.batch * world * args.steps
     value = units / elapsed
     ms_step = 1e3 * elapsed / args.steps
-    algo = ALGO_BYTES[args.workload]
+    algo = ALGO_BYTES[workload]
     achieved = value / world * algo / 1e9          # per-GPU algorithmic GB/s
     kernels = extra.get("kernels", {})
     dom = max(kernels.items(), key=lambda kv: kv[1]["ms_total"])[0] if kernels else None
-    if args.workload == "ntt" and dom:
+    if workload == "ntt" and dom:
         # NTT-only: each of the two kernels (forward, inverse) handles a whole unit half: 1024 algorithmic bytes per
         # polynomial and launch; the roofline entry is the dominant kernel's, from its own HIP-event duration.
         per_launch = 1024.0 * args.batch
@@ -317,23 +328,28 @@ def main():
                 "dominant_kernel_ms_avg": kernels[dom]["ms_avg"] if dom else None,
                 "dominant_kernel_share": kernels[dom]["ms_total"] / sum(k["ms_total"] for k in kernels.values()) if dom else None}
     # HBM traffic from the PMC counters is collected off-line (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE cannot run inside
-    # this process); the committed summary of the same command is attached when it matches the workload and batch
-    tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic_%s.json" % args.workload)
-    if os.path.exists(tpath) and args.batch == 1 << 20:
+    # this process).  The committed summary is attached only when it was measured on THIS build (same source hash), for
+    # this workload, batch and chunking; otherwise traffic stays null.
+    tpath = os.path.join(ROOT, "profiles", "r02_pmc_traffic_%s.json" % workload)
+    if os.path.exists(tpath):
         t = json.load(open(tpath))
-        roofline["traffic"] = t["hbm_bytes_per_step_corrected"]
-        roofline["traffic_note"] = "bytes per step from %s: (2*FETCH_SIZE + WRITE_SIZE)*1024; raw = %.3g" % (
-            os.path.relpath(tpath, ROOT), t["hbm_bytes_per_step_raw"])
-    if args.workload in ("kem512", "kem768", "kem1024") and dom == "k_sample_main":
+        if t.get("source_id") == source_id() and t.get("batch") == args.batch:
+            roofline["traffic"] = t["hbm_bytes_per_step_corrected"]
+            roofline["traffic_note"] = "bytes per step from %s (git %s, source_id %s): (2*FETCH_SIZE + WRITE_SIZE)*1024; raw = %.3g" % (
+                os.path.relpath(tpath, ROOT), t.get("git_head", "?"), t["source_id"], t["hbm_bytes_per_step_raw"])
+        else:
+            roofline["traffic_note"] = "%s was measured on another build (source_id %s != %s) or batch: not attached" % (
+                os.path.relpath(tpath, ROOT), t.get("source_id"), source_id())
+    if workload in ("kem512", "kem768", "kem1024") and dom == "k_sample_main":
         # the dominant kernel's own HBM bytes per launch: per item it reads rho and r (32 B each) and
-        # writes the k x k matrix (512 B per polynomial) and the PRF rows (128 B, 192 B for eta = 3)
-        k = {"kem512": 2, "kem768": 3, "kem1024": 4}[args.workload]
-        per_item = 64 + 512 * k * k + (2 * k + 1) * 128 + (k * 64 if k == 2 else 0)
+        # writes the k x k matrix (A_POLY_BYTES per polynomial) and the PRF rows (128 B, 192 B for eta = 3)
+        k = {"kem512": 2, "kem768": 3, "kem1024": 4}[workload]
+        per_item = 64 + extra.get("a_poly_bytes", 512) * k * k + (2 * k + 1) * 128 + (k * 64 if k == 2 else 0)
         chunk = min(extra.get("chunk_items") or (1 << 18), args.batch)
         roofline["dominant_kernel_bytes_per_launch"] = per_item * chunk
         roofline["dominant_kernel_GBps"] = per_item * chunk / (kernels[dom]["ms_avg"] * 1e-3) / 1e9
         roofline["dominant_kernel_frac"] = roofline["dominant_kernel_GBps"] / HBM_PEAK_GBS
-    if args.workload == "kem768":
+    if workload == "kem768":
         # the bound that actually binds: 95 Keccak-f per pair x 24 rounds x 180 VALU (122 full-rate + 58
         # v_alignbit_b32 at ~0.58x rate, profiles/r01_valu_ubench.txt), + NTT / codec / sampling work
         keccak_ops = 95 * KECCAK_PERM_LANE_OPS
@@ -343,13 +359,71 @@ def main():
                                "frac_keccak_only": value / world * keccak_ops / VALU_PEAK_LANE_OPS,
                                "note": "the pass runs into the socket power limit (rocm-smi: ~1340 W, shader clock ~2.07 GHz instead of "
                                        "2.4 GHz; DESIGN.md section 5, profiles/r01_clock_power_watch.txt, profiles/r01_power_ubench.txt)"}
-    line = {"metric": metric, "value": value, "unit": unit, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype,
-            "data": "synthetic", "config": {"workload": wl, "batch_per_gpu": args.batch, "parallelism": "shard%d (no collectives)" % world,
+    return {"value": value, "ms_per_step": ms_step, "correct": ok, "roofline": roofline, "kernels": kernels}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None,
+                    help="timed steps (default 20: ~0.4 s, long enough for the power-capped clock to settle; 200 for the "
+                         "sub-millisecond NTT workload)")
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="kem768", choices=("kem768", "kem1024", "kem512", "ntt", "kem768_shared"))
+    ap.add_argument("--batch", type=int, default=1 << 20, help="items per GPU per step (BASELINE: 2^20)")
+    ap.add_argument("--chunk", type=int, default=0, help="engine chunk size in items (0 = library default)")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-also", action="store_true", help="skip the configs[1] / configs[3] legs of the default run")
+    ap.add_argument("--rehearse", action="store_true",
+                    help="N > 1 ranks on fewer GPUs: ranks share the visible GPU(s), barrier over gloo (automatic when the node "
+                         "has fewer GPUs than ranks)")
+    args = ap.parse_args()
+    if args.steps is None:
+        args.steps = 200 if args.workload == "ntt" else 20
+
+    rank, world, local = dist_setup(args.gpus, args.rehearse)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the engine has no CPU fallback")
+    device = torch.device("cuda", local)
+    torch.cuda.set_device(device)
+
+    elapsed, ok, extra = run_workload(args.workload, args, rank, world, device)
+    metric, unit, wl, dtype = WORKLOAD_META[args.workload]
+    dtype = dtype or KEM_DTYPE
+
+    also = {}
+    if world == 1 and args.workload == "kem768" and not args.no_also:
+        # BASELINE configs[1] and configs[3] in the same process, so that they are driver-observed too (not the headline:
+        # `value` above is configs[2]); same timing discipline, their own step counts
+        for wl2, steps2 in (("ntt", 200), ("kem1024", 10)):
+            a2 = argparse.Namespace(**vars(args))
+            a2.workload, a2.steps, a2.warmup, a2.no_cpu = wl2, steps2, 2, True
+            el2, ok2, ex2 = run_workload(wl2, a2, rank, world, device)
+            e2 = entry(wl2, a2, el2, ok2, ex2, world)
+            m2 = WORKLOAD_META[wl2]
+            e2.update({"metric": m2[0], "unit": m2[1], "steps": steps2, "warmup": 2, "config": {"workload": m2[2] % a2.batch}})
+            also[wl2] = e2
+            ok = ok and ok2
+            torch.cuda.empty_cache()
+
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+    if rank != 0:
+        return
+    e = entry(args.workload, args, elapsed, ok, extra, world)
+    par = "shard%d (no collectives)" % world
+    if SHARED_GPU:
+        par += "; REHEARSAL: %d ranks share %d GPU(s), barrier over gloo - not a scaling measurement" % (world, torch.cuda.device_count())
+    line = {"metric": metric, "value": e["value"], "unit": unit, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": e["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype,
+            "data": "synthetic", "config": {"workload": wl % args.batch, "batch_per_gpu": args.batch, "parallelism": par,
                                             "chunk_items": extra.get("chunk_items")},
-            "correct": ok, "roofline": roofline, "kernels": kernels}
+            "correct": ok, "roofline": e["roofline"], "kernels": e["kernels"]}
     if "cpu_baseline" in extra:
         line["cpu_baseline"] = extra["cpu_baseline"]
+    if also:
+        line["also"] = also
     print(json.dumps(line))
     if not ok:
         sys.exit(3)

@@ -36,6 +36,11 @@ ABI_SYMBOLS = (
     "mlkem_sample_ntt", "mlkem_sample_cbd",
     "mlkem_keygen_random", "mlkem_encaps_random",
     "mlkem_cells_to_bytes_dev", "mlkem_bytes_to_cells_dev", "mlkem_keygen_stream", "mlkem_encaps_stream", "mlkem_decaps_stream", "mlkem_stream_release",
+    "mlkem_compress_dev", "mlkem_decompress_dev", "mlkem_compress", "mlkem_decompress", "mlkem_sha3_pad_suffix",
+    "mlkem_selftest_count", "mlkem_selftest", "mlkem_host_release", "mlkem_host_register", "mlkem_host_unregister",
+    "mlkem_multi_create", "mlkem_multi_destroy", "mlkem_multi_members", "mlkem_multi_device", "mlkem_shard_range",
+    "mlkem_keygen_multi", "mlkem_encaps_multi", "mlkem_decaps_multi",
+    "mlkem_keygen_multi_dev", "mlkem_encaps_multi_dev", "mlkem_decaps_multi_dev", "mlkem_multi_sync",
 )
 SHIM_SYMBOLS = ("init", "KEM_KeyGen", "KEM_Encaps", "KEM_Decaps", "ml_errno", "sha3_b", "sha3_h", "sha3_s", "h2b", "b2h",
                 "SampleNTT", "SamplePolyCBD", "NTT", "InverseNTT")
@@ -106,6 +111,30 @@ def load_library():
     L.mlkem_keygen_stream.argtypes = [i32, sz, vp, vp, vp, vp, sz]
     L.mlkem_encaps_stream.argtypes = [i32, sz, vp, vp, vp, vp, sz]
     L.mlkem_decaps_stream.argtypes = [i32, sz, vp, vp, vp, vp, sz]
+    L.mlkem_compress_dev.argtypes = [vp, i32, sz, vp, vp, vp]
+    L.mlkem_decompress_dev.argtypes = [vp, i32, sz, vp, vp, vp]
+    L.mlkem_compress.argtypes = [i32, sz, vp, vp]
+    L.mlkem_decompress.argtypes = [i32, sz, vp, vp]
+    L.mlkem_sha3_pad_suffix.argtypes = [vp, sz, vp, C.c_uint, C.c_uint, vp, sz]
+    L.mlkem_selftest.argtypes = [vp, i32, C.POINTER(C.c_ulonglong)]
+    L.mlkem_host_release.restype = None
+    L.mlkem_stream_release.restype = None
+    L.mlkem_host_register.argtypes = [vp, sz]
+    L.mlkem_host_unregister.argtypes = [vp]
+    L.mlkem_multi_create.argtypes = [C.POINTER(vp), i32, C.POINTER(C.c_int), sz]
+    L.mlkem_multi_destroy.argtypes = [vp]
+    L.mlkem_multi_destroy.restype = None
+    L.mlkem_multi_members.argtypes = [vp]
+    L.mlkem_multi_device.argtypes = [vp, i32]
+    L.mlkem_shard_range.argtypes = [sz, i32, i32, C.POINTER(sz), C.POINTER(sz)]
+    L.mlkem_keygen_multi.argtypes = [vp, i32, sz, vp, vp, vp, vp, sz]
+    L.mlkem_encaps_multi.argtypes = [vp, i32, sz, vp, vp, vp, vp, sz]
+    L.mlkem_decaps_multi.argtypes = [vp, i32, sz, vp, vp, vp, vp, sz]
+    pp = C.POINTER(vp)
+    L.mlkem_keygen_multi_dev.argtypes = [vp, i32, C.POINTER(sz), pp, pp, pp, pp]
+    L.mlkem_encaps_multi_dev.argtypes = [vp, i32, C.POINTER(sz), pp, pp, pp, pp]
+    L.mlkem_decaps_multi_dev.argtypes = [vp, i32, C.POINTER(sz), pp, pp, pp, pp]
+    L.mlkem_multi_sync.argtypes = [vp]
     _lib = L
     return L
 
@@ -190,9 +219,21 @@ class MLKEM:
             raise MLKEMError(-3, f"type check failed: expected rows of {last}, got {tuple(t.shape)} (reference ml_errno -3)")
         return t
 
-    def _out(self, n, last, dtype=None):
+    def _out(self, n, last, dtype=None, given=None):
+        """A fresh [n, last] output (or [n] when last is None), or the caller's tensor after checking that the raw pointer
+        handed to the C-ABI really is n x last elements of `dtype`, contiguous, on this engine's device."""
         torch = self.torch
-        return torch.empty((n, last), dtype=dtype or torch.uint8, device=self.device)
+        dtype = dtype or torch.uint8
+        shape = (n,) if last is None else (n, last)
+        if given is None:
+            return torch.empty(shape, dtype=dtype, device=self.device)
+        if not isinstance(given, torch.Tensor):
+            raise MLKEMError(-101, "output must be a torch tensor")
+        if given.device != self.device or given.dtype != dtype or tuple(given.shape) != shape or not given.is_contiguous():
+            raise MLKEMError(-101, f"output tensor must be contiguous {dtype} {shape} on {self.device}, got "
+                                   f"{given.dtype} {tuple(given.shape)} on {given.device}"
+                                   f"{'' if given.is_contiguous() else ' (non-contiguous)'}")
+        return given
 
     @property
     def scratch_bytes(self):
@@ -206,8 +247,8 @@ class MLKEM:
         n = d.shape[0]
         if z.shape[0] != n:
             raise MLKEMError(-101, "d and z batch sizes differ")
-        ek = ek if ek is not None else self._out(n, self.ek_len)
-        dk = dk if dk is not None else self._out(n, self.dk_len)
+        ek = self._out(n, self.ek_len, given=ek)
+        dk = self._out(n, self.dk_len, given=dk)
         self._check(self.lib.mlkem_keygen_dev(self._ctx, self.param_set, n, d.data_ptr(), z.data_ptr(), ek.data_ptr(),
                                               dk.data_ptr(), self._stream()))
         return ek, dk
@@ -220,8 +261,8 @@ class MLKEM:
         n = m.shape[0]
         if ek.shape[0] != n:
             raise MLKEMError(-101, "ek and m batch sizes differ")
-        c = c if c is not None else self._out(n, self.c_len)
-        K = K if K is not None else self._out(n, 32)
+        c = self._out(n, self.c_len, given=c)
+        K = self._out(n, 32, given=K)
         if return_status:
             st = self.torch.empty(n, dtype=self.torch.int32, device=self.device)
             self._check(self.lib.mlkem_encaps_status_dev(self._ctx, self.param_set, n, ek.data_ptr(), m.data_ptr(), c.data_ptr(),
@@ -239,9 +280,9 @@ class MLKEM:
         n = c.shape[0]
         if dk.shape[0] != n:
             raise MLKEMError(-101, "dk and c batch sizes differ")
-        K = K if K is not None else self._out(n, 32)
-        if hash_check and status is None:
-            status = torch.empty(n, dtype=torch.int32, device=self.device)
+        K = self._out(n, 32, given=K)
+        if hash_check:
+            status = self._out(n, None, torch.int32, given=status)
         sp = status.data_ptr() if hash_check else None
         self._check(self.lib.mlkem_decaps_dev(self._ctx, self.param_set, n, dk.data_ptr(), c.data_ptr(), K.data_ptr(), sp,
                                               self._stream()))
@@ -371,6 +412,37 @@ class MLKEM:
         self._check(self.lib.mlkem_decode_decompress_dev(self._ctx, d, b.shape[0], b.data_ptr(), out.data_ptr(), self._stream()))
         return out
 
+    def compress(self, x, d):
+        """Compress(x, d) (ml_kem.c:83) value by value, any d in 1..12, any 12-bit x: tensor of int16/uint16 -> same shape."""
+        return self._compress(x, d, False)
+
+    def decompress(self, y, d):
+        """Decompress(y, d) (ml_kem.c:104) value by value, any d in 1..12."""
+        return self._compress(y, d, True)
+
+    def _compress(self, v, d, inverse):
+        torch = self.torch
+        if not isinstance(v, torch.Tensor):
+            v = torch.as_tensor(v)
+        if v.dtype == torch.uint16:
+            v = v.view(torch.int16)
+        v = v.to(device=self.device, dtype=torch.int16).contiguous()
+        out = torch.empty_like(v)
+        fn = self.lib.mlkem_decompress_dev if inverse else self.lib.mlkem_compress_dev
+        self._check(fn(self._ctx, int(d), v.numel(), v.data_ptr(), out.data_ptr(), self._stream()))
+        return out
+
+    def selftest(self):
+        """On-device exhaustive sweeps of the exact fp32-pipe arithmetic (include/mlkem_batch.h: mlkem_selftest);
+        returns the list of violation counts, one per sweep (all zero = every helper exact over its whole domain)."""
+        self.torch.cuda.synchronize(self.device)
+        out = []
+        for w in range(self.lib.mlkem_selftest_count()):
+            v = C.c_ulonglong(12345)
+            self._check(self.lib.mlkem_selftest(self._ctx, w, C.byref(v)))
+            out.append(v.value)
+        return out
+
     def prf(self, in33, eta):
         """PRF (ml_kem.c:496; SHAKE128 in the reference): [n,33] (s || b) -> [n,64*eta]."""
         s = self._dev(in33, self.torch.uint8, 33)
@@ -418,19 +490,22 @@ class MLKEM:
         self._check(self.lib.mlkem_bytes_to_cells_dev(self._ctx, data.numel(), data.data_ptr(), out.data_ptr(), self._stream()))
         return out.reshape(data.shape)
 
-    def sha3_bits(self, bits_list, xof, rate, outlen):
+    def sha3_bits(self, bits_list, xof, rate, outlen, suffix=None):
         """SHA-3 / SHAKE of bit-granular messages (sha3_b, sha3.c:408): `bits_list` = equal-length sequences of 0/1;
-        suffix + pad10*1 on the host (mlkem_sha3_pad_bits), sponge on the device.  -> [n, outlen] bytes."""
+        suffix + pad10*1 on the host (mlkem_sha3_pad_suffix), sponge on the device.  -> [n, outlen] bytes.
+        `suffix`: explicit suffix bits (e.g. (1, 1) = RawSHAKE) instead of the hash "01" / XOF "1111"."""
         import numpy as np
         torch = self.torch
         n = len(bits_list)
         nbits = len(bits_list[0]) if n else 0
-        nblocks = (nbits + (4 if xof else 2) + 2 + 8 * rate - 1) // (8 * rate)
+        sfx = np.ascontiguousarray(suffix if suffix is not None else ((1, 1, 1, 1) if xof else (0, 1)), np.uint8)
+        nblocks = (nbits + sfx.size + 2 + 8 * rate - 1) // (8 * rate)
         padded = np.zeros((n, nblocks * rate), np.uint8)
         for i, b in enumerate(bits_list):
             b = np.ascontiguousarray(b, np.uint8)
             assert b.size == nbits
-            rc = self.lib.mlkem_sha3_pad_bits(b.ctypes.data, nbits, int(bool(xof)), rate, padded[i].ctypes.data, padded[i].size)
+            rc = self.lib.mlkem_sha3_pad_suffix(b.ctypes.data, nbits, sfx.ctypes.data, sfx.size, rate, padded[i].ctypes.data,
+                                                padded[i].size)
             if rc != nblocks:
                 raise MLKEMError(rc, "sha3 padding failed")
         dp = torch.from_numpy(padded).to(self.device)
@@ -447,6 +522,129 @@ class MLKEM:
     SampleNTT = sample_ntt
     SamplePolyCBD = sample_cbd
     PRF = prf
+
+
+class MLKEMMulti:
+    """In-process sharding over several devices (include/mlkem_batch.h: mlkem_multi_*): member r of R works on
+    the contiguous item range shard_range(n, r, R) on its own device; no exchange between members, no collective.
+    `devices` may repeat a device (rehearsal of the sharded path on one GPU)."""
+
+    def __init__(self, param_set=768, devices=None, chunk_items=0):
+        import torch
+        self.torch = torch
+        self.lib = load_library()
+        self.ek_len, self.dk_len, self.c_len = sizes(param_set)
+        self.param_set = param_set
+        if not torch.cuda.is_available():
+            raise MLKEMError(-100, "no HIP device visible (the engine has no CPU fallback)")
+        devices = list(range(torch.cuda.device_count())) if devices is None else list(devices)
+        arr = (C.c_int * len(devices))(*devices)
+        h = C.c_void_p()
+        rc = self.lib.mlkem_multi_create(C.byref(h), len(devices), arr, chunk_items)
+        if rc:
+            raise MLKEMError(rc, self.lib.mlkem_strerror(rc).decode())
+        self._mm = h
+        self.devices = devices
+        self.members = len(devices)
+
+    def close(self):
+        if getattr(self, "_mm", None):
+            self.lib.mlkem_multi_destroy(self._mm)
+            self._mm = None
+
+    __del__ = close
+
+    def _check(self, rc):
+        if rc != 0:
+            raise MLKEMError(rc, self.lib.mlkem_strerror(rc).decode() + " [" + self.lib.mlkem_last_hip_error().decode() + "]")
+
+    def ranges(self, n):
+        return [shard_range(n, r, self.members) for r in range(self.members)]
+
+    # -- host-resident batches (numpy uint8 arrays), one host thread + streaming engine per member --------------------
+    def _host(self, a, last):
+        import numpy as np
+        a = np.ascontiguousarray(a, np.uint8).reshape(-1, last)
+        return a
+
+    def keygen(self, d, z, chunk_items=0):
+        import numpy as np
+        d, z = self._host(d, 32), self._host(z, 32)
+        n = d.shape[0]
+        ek, dk = np.empty((n, self.ek_len), np.uint8), np.empty((n, self.dk_len), np.uint8)
+        self._check(self.lib.mlkem_keygen_multi(self._mm, self.param_set, n, d.ctypes.data, z.ctypes.data, ek.ctypes.data,
+                                                dk.ctypes.data, chunk_items))
+        return ek, dk
+
+    def encaps(self, ek, m, chunk_items=0):
+        import numpy as np
+        ek, m = self._host(ek, self.ek_len), self._host(m, 32)
+        n = m.shape[0]
+        c, K = np.empty((n, self.c_len), np.uint8), np.empty((n, 32), np.uint8)
+        self._check(self.lib.mlkem_encaps_multi(self._mm, self.param_set, n, ek.ctypes.data, m.ctypes.data, c.ctypes.data,
+                                                K.ctypes.data, chunk_items))
+        return c, K
+
+    def decaps(self, dk, c, chunk_items=0):
+        import numpy as np
+        dk, c = self._host(dk, self.dk_len), self._host(c, self.c_len)
+        n = c.shape[0]
+        K, st = np.empty((n, 32), np.uint8), np.empty(n, np.int32)
+        self._check(self.lib.mlkem_decaps_multi(self._mm, self.param_set, n, dk.ctypes.data, c.ctypes.data, K.ctypes.data,
+                                                st.ctypes.data, chunk_items))
+        return K, st
+
+    # -- device-resident shards: lists (one tensor per member, on that member's device) ---------------------------------
+    def _shards(self, ts, last, dtype=None):
+        torch = self.torch
+        dtype = dtype or torch.uint8
+        if len(ts) != self.members:
+            raise MLKEMError(-101, f"need one shard per member ({self.members}), got {len(ts)}")
+        for r, t in enumerate(ts):
+            want_dev = torch.device("cuda", self.devices[r])
+            ok = isinstance(t, torch.Tensor) and t.device == want_dev and t.dtype == dtype and t.is_contiguous() and \
+                (t.dim() == 2 and t.shape[1] == last if last is not None else t.dim() == 1)
+            if not ok:
+                raise MLKEMError(-101, f"shard {r}: expected a contiguous {dtype} tensor [n, {last}] on {want_dev}")
+        return (C.c_void_p * self.members)(*[t.data_ptr() for t in ts])
+
+    def _sizes(self, ts, *others):
+        ns = [int(t.shape[0]) for t in ts]
+        for o in others:
+            if [int(t.shape[0]) for t in o] != ns:
+                raise MLKEMError(-101, "shard sizes differ between operands")
+        return (C.c_size_t * self.members)(*ns), ns
+
+    def _empty(self, ns, last, dtype=None):
+        torch = self.torch
+        return [torch.empty((n, last) if last is not None else (n,), dtype=dtype or torch.uint8, device=torch.device("cuda", dv))
+                for n, dv in zip(ns, self.devices)]
+
+    def keygen_dev(self, d, z):
+        """shards d[r], z[r] [n_r, 32] on device r -> ek[r], dk[r]; enqueued, call sync() before reading."""
+        ns_c, ns = self._sizes(d, z)
+        ek, dk = self._empty(ns, self.ek_len), self._empty(ns, self.dk_len)
+        self._check(self.lib.mlkem_keygen_multi_dev(self._mm, self.param_set, ns_c, self._shards(d, 32), self._shards(z, 32),
+                                                    self._shards(ek, self.ek_len), self._shards(dk, self.dk_len)))
+        return ek, dk
+
+    def encaps_dev(self, ek, m):
+        ns_c, ns = self._sizes(m, ek)
+        c, K = self._empty(ns, self.c_len), self._empty(ns, 32)
+        self._check(self.lib.mlkem_encaps_multi_dev(self._mm, self.param_set, ns_c, self._shards(ek, self.ek_len), self._shards(m, 32),
+                                                    self._shards(c, self.c_len), self._shards(K, 32)))
+        return c, K
+
+    def decaps_dev(self, dk, c):
+        ns_c, ns = self._sizes(c, dk)
+        K, st = self._empty(ns, 32), self._empty(ns, None, self.torch.int32)
+        self._check(self.lib.mlkem_decaps_multi_dev(self._mm, self.param_set, ns_c, self._shards(dk, self.dk_len),
+                                                    self._shards(c, self.c_len), self._shards(K, 32),
+                                                    self._shards(st, None, self.torch.int32)))
+        return K, st
+
+    def sync(self):
+        self._check(self.lib.mlkem_multi_sync(self._mm))
 
 
 def shard_range(n_total, rank, world):

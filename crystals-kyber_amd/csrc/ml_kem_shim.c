@@ -234,7 +234,11 @@ union hex* b2h(const union bit* S, unsigned int n) {   /* sha3.c:367-396 */
 union bit* sha3_b(const union bit* bstr, unsigned int n, unsigned int d, unsigned int c, union bit sfx[4]) {   /* sha3.c:408-436 */
     if (c >= 1600 || ((1600 - c) % 8) != 0) { report("ml_kem shim - sha3_b()", "unsupported capacity"); return NULL; }
     const unsigned rate = (1600 - c) / 8;
-    const int xof = sfx[2].b == 1;   /* sha3.c:414: four suffix bits 1111 for the XOFs, two bits 01 otherwise */
+    /* sha3.c:414-429: four suffix bits when sfx[2] is set (the XOFs' 1111), two otherwise (hash 01, RawSHAKE 11);
+     * the caller's bits are appended verbatim */
+    const unsigned nsfx = sfx[2].b == 1 ? 4u : 2u;
+    unsigned char sbits[4];
+    for (unsigned i = 0; i < nsfx; i++) sbits[i] = (unsigned char)(sfx[i].b & 1u);
     const size_t cap = ((size_t)n + 6 + 8 * rate) / (8 * rate) * rate + rate;
     unsigned char* bits = (unsigned char*)malloc(n ? n : 1);
     unsigned char* padded = (unsigned char*)malloc(cap);
@@ -242,7 +246,7 @@ union bit* sha3_b(const union bit* bstr, unsigned int n, unsigned int d, unsigne
     union bit* D = NULL;
     if (bits && padded && out) {
         for (unsigned int i = 0; i < n; i++) bits[i] = (unsigned char)(bstr[i].b & 1u);
-        int nblocks = mlkem_sha3_pad_bits(bits, n, xof, rate, padded, cap);
+        int nblocks = mlkem_sha3_pad_suffix(bits, n, sbits, nsfx, rate, padded, cap);
         int rc = nblocks > 0 ? mlkem_keccak_sponge(rate, 1, padded, (unsigned)nblocks, out, (d + 7) / 8) : nblocks;
         if (!engine_failed("ml_kem shim - sha3_b()", rc)) {
             D = (union bit*)calloc(d ? d : 1, sizeof(union bit));

@@ -501,6 +501,38 @@ __global__ void __launch_bounds__(WAVE * ARITH_WAVES) k_decode_batch(size_t n, c
     }
 }
 
+// Compress_d / Decompress_d (ml_kem.c:83-97 / :104-119) value by value for ANY d in 1..12 and ANY 12-bit input, with the
+// reference's field widths: inputs are taken mod 2^12 (`union integer.t`), the dividend lives in 24 bits (it always fits),
+// the rounded quotient wraps at 12 bits, d = 12 is the identity.  The K-PKE kernels only ever need d in {1, 4, 5, 10, 11}
+// on reduced inputs (compress_f / decompress_d above); this is the general entry the reference's CompressDecompress test
+// (d = 1..12) exercises.  Element-wise streaming kernel, 8 values (16 B) per lane and iteration.
+__device__ __forceinline__ unsigned compress_any(unsigned x, int d) {
+    x &= 0xFFFu;
+    if (d >= 12) return x;
+    const unsigned num = x << d, quo = div_q(num), rem = num - quo * (unsigned)KQ;   // num < 2^23
+    return (quo + (rem > (unsigned)(KQ / 2) ? 1u : 0u)) & ((1u << d) - 1u);
+}
+__device__ __forceinline__ unsigned decompress_any(unsigned y, int d) {
+    y &= 0xFFFu;
+    if (d >= 12) return y;
+    const unsigned t = (unsigned)KQ * y;                                            // < 2^24
+    return ((t >> d) + ((t & ((1u << d) - 1u)) >= (1u << (d - 1)) ? 1u : 0u)) & 0xFFFu;
+}
+template <bool DECOMPRESS>
+__global__ void __launch_bounds__(256) k_compress_values(size_t n, int d, const uint16_t* __restrict__ in, uint16_t* __restrict__ out) {
+    const size_t groups = n / 8, stride = (size_t)gridDim.x * blockDim.x;
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    auto f = [d](unsigned v) { return DECOMPRESS ? decompress_any(v, d) : compress_any(v, d); };
+    for (size_t g = t; g < groups; g += stride) {
+        const uint4 v = reinterpret_cast<const uint4*>(in)[g];
+        uint4 o;
+        o.x = f(v.x & 0xFFFFu) | (f(v.x >> 16) << 16); o.y = f(v.y & 0xFFFFu) | (f(v.y >> 16) << 16);
+        o.z = f(v.z & 0xFFFFu) | (f(v.z >> 16) << 16); o.w = f(v.w & 0xFFFFu) | (f(v.w >> 16) << 16);
+        reinterpret_cast<uint4*>(out)[g] = o;
+    }
+    for (size_t i = groups * 8 + t; i < n; i += stride) out[i] = (uint16_t)f(in[i]);
+}
+
 // ================================================================================================
 // layout converters: the reference keeps every "byte" in a 4-byte `union byte` cell (value in bits
 // 0-7, upper 24 bits undefined: ml_kem.h:35-38).  Pure streaming kernels, 16 cells (64 B in / 16 B out, or

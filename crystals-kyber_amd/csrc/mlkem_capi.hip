@@ -4,6 +4,7 @@
 // MLKEM_ERR_NO_DEVICE / a HIP error.  The CPU oracle under oracle/ is test infrastructure and is never
 // linked or loaded by this library.
 #include "mlkem_pipeline.hpp"
+#include "mlkem_selftest.hpp"
 
 #include "../../include/mlkem_batch.h"
 
@@ -13,6 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string.h>
+#include <map>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -368,6 +370,35 @@ int mlkem_decode_decompress_dev(mlkem_ctx* ctx, int d, size_t n, const uint8_t* 
     HIP_TRY(hipGetLastError());
     return MLKEM_OK;
 }
+int mlkem_compress_dev(mlkem_ctx* ctx, int d, size_t n, const uint16_t* x, uint16_t* y, void* stream) {
+    if (!ctx_ok(ctx) || (n && (!x || !y)) || !aligned16(x) || !aligned16(y)) return MLKEM_ERR_ARG;
+    if (compress_values_launch(static_cast<hipStream_t>(stream), false, d, n, x, y)) return MLKEM_ERR_ARG;
+    HIP_TRY(hipGetLastError());
+    return MLKEM_OK;
+}
+int mlkem_decompress_dev(mlkem_ctx* ctx, int d, size_t n, const uint16_t* y, uint16_t* x, void* stream) {
+    if (!ctx_ok(ctx) || (n && (!x || !y)) || !aligned16(x) || !aligned16(y)) return MLKEM_ERR_ARG;
+    if (compress_values_launch(static_cast<hipStream_t>(stream), true, d, n, y, x)) return MLKEM_ERR_ARG;
+    HIP_TRY(hipGetLastError());
+    return MLKEM_OK;
+}
+// On-device exhaustive self-test of the exact fp32-pipe arithmetic (mlkem_selftest.hpp).  Runs sweep `which`
+// (0 .. mlkem_selftest_count()-1) on the context's device, synchronises, and stores the number of violations.
+int mlkem_selftest_count(void) { return SELFTEST_SWEEPS; }
+int mlkem_selftest(mlkem_ctx* ctx, int which, unsigned long long* violations) {
+    if (!ctx_ok(ctx) || !violations || which < 0 || which >= SELFTEST_SWEEPS) return MLKEM_ERR_ARG;
+    unsigned long long* d = nullptr;
+    HIP_TRY(hipMalloc(&d, sizeof *d));
+    int rc = MLKEM_OK;
+    if (!hip_ok(hipMemset(d, 0, sizeof *d), "hipMemset")) rc = MLKEM_ERR_NO_DEVICE;
+    if (rc == MLKEM_OK) {
+        k_selftest<<<dim3(256 * 8), dim3(256), 0, nullptr>>>(which, d);
+        if (!hip_ok(hipGetLastError(), "k_selftest") || !hip_ok(hipMemcpy(violations, d, sizeof *d, hipMemcpyDeviceToHost), "hipMemcpy"))
+            rc = MLKEM_ERR_NO_DEVICE;
+    }
+    (void)hipFree(d);
+    return rc;
+}
 int mlkem_prf_dev(mlkem_ctx* ctx, int eta, size_t n, const uint8_t* in33, uint8_t* out, void* stream) {
     if (!ctx_ok(ctx) || (n && (!in33 || !out)) || !aligned16(out)) return MLKEM_ERR_ARG;
     if (n && prf_launch(static_cast<hipStream_t>(stream), eta, n, in33, out)) return MLKEM_ERR_ARG;
@@ -401,57 +432,50 @@ int mlkem_bytes_to_cells_dev(mlkem_ctx* ctx, size_t n, const uint8_t* bytes, uin
     return MLKEM_OK;
 }
 
-// Pure host helper (no device work): message bits (one per byte) + SHA-3 suffix + pad10*1 -> whole rate blocks.
-// sha3.c:408-436 (suffix "01" / "1111") and :226-240 (pad), without the reference's latent bug for
-// (n + suffix + 2) == 0 mod r.  Returns the number of blocks, or a negative error.
-int mlkem_sha3_pad_bits(const uint8_t* msg_bits, size_t nbits, int xof, unsigned rate, uint8_t* padded, size_t padded_cap) {
-    if (rate == 0 || rate > 200 || (rate & 7)) return MLKEM_ERR_ARG;
-    const size_t sbits = xof ? 4 : 2, rbits = (size_t)rate * 8;
+// Pure host helpers (no device work): message bits (one per byte) + SHA-3 suffix + pad10*1 -> whole rate blocks.
+// sha3.c:408-436 (the caller's suffix bits appended verbatim: two or four of them there) and :226-240 (pad), without the
+// reference's latent bug for (n + suffix + 2) == 0 mod r.  Returns the number of blocks, or a negative error.
+int mlkem_sha3_pad_suffix(const uint8_t* msg_bits, size_t nbits, const uint8_t* sfx_bits, unsigned nsfx, unsigned rate,
+                          uint8_t* padded, size_t padded_cap) {
+    if (rate == 0 || rate > 200 || (rate & 7) || nsfx > 8 || (nsfx && !sfx_bits)) return MLKEM_ERR_ARG;
+    const size_t sbits = nsfx, rbits = (size_t)rate * 8;
     const size_t nblocks = (nbits + sbits + 2 + rbits - 1) / rbits;
     if (nblocks * rate > padded_cap || !padded || (nbits && !msg_bits)) return MLKEM_ERR_ARG;
     memset(padded, 0, nblocks * rate);
     auto setbit = [&](size_t pos) { padded[pos >> 3] |= (uint8_t)(1u << (pos & 7)); };
     for (size_t i = 0; i < nbits; i++)
         if (msg_bits[i] & 1) setbit(i);
-    if (xof) { setbit(nbits); setbit(nbits + 1); setbit(nbits + 2); setbit(nbits + 3); }
-    else setbit(nbits + 1);
+    for (size_t i = 0; i < sbits; i++)
+        if (sfx_bits[i] & 1) setbit(nbits + i);
     setbit(nbits + sbits);               // first pad bit
     setbit(nblocks * rbits - 1);         // last pad bit
     return (int)nblocks;
 }
+int mlkem_sha3_pad_bits(const uint8_t* msg_bits, size_t nbits, int xof, unsigned rate, uint8_t* padded, size_t padded_cap) {
+    static const uint8_t hash_sfx[2] = {0, 1}, xof_sfx[4] = {1, 1, 1, 1};
+    return mlkem_sha3_pad_suffix(msg_bits, nbits, xof ? xof_sfx : hash_sfx, xof ? 4u : 2u, rate, padded, padded_cap);
+}
 
 }   // extern "C"
 
-// ---- host-pointer variants -----------------------------------------------------------------------------
+// ---- per-device state of the host-pointer entry points -------------------------------------------------------------
+// Everything the host-pointer calls keep between calls is keyed by the HIP device that is current when the call is made:
+// a small context for the primitives (NTT, SampleNTT, SamplePolyCBD, sponge: they use no scratch) and a streaming engine
+// (streams, events, device + pinned staging buffers, a context sized for one chunk).  Two host threads working on two
+// devices therefore share nothing and take different locks.  mlkem_host_release() wipes and frees all of it.
 namespace {
 
-std::mutex g_host_mu;
-mlkem_ctx* g_host_ctx = nullptr;
-
-// makes the host context's device current for the duration of a host-pointer call and restores the caller's afterwards
+// makes `dev` current for the duration of a call and restores the caller's device afterwards
 struct DeviceGuard {
-    int prev = -1;
-    void enter(int dev) {
-        int cur = -1;
-        if (hipGetDevice(&cur) == hipSuccess && cur != dev && hipSetDevice(dev) == hipSuccess) prev = cur;
+    int orig = -1;
+    bool enter(int dev) {   // may be called repeatedly; the device current at the first call is restored at the end
+        if (orig < 0 && hipGetDevice(&orig) != hipSuccess) orig = -1;
+        return hipSetDevice(dev) == hipSuccess;
     }
-    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+    ~DeviceGuard() { if (orig >= 0) (void)hipSetDevice(orig); }
 };
 
-// the host-pointer entry points share one lazily created context on the device that is current at the first call
-int host_ctx(mlkem_ctx** out, DeviceGuard& guard) {
-    if (!g_host_ctx) {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess) dev = 0;
-        int rc = mlkem_ctx_create(&g_host_ctx, dev, (size_t)1 << 16);
-        if (rc) return rc;
-    }
-    guard.enter(g_host_ctx->device);
-    *out = g_host_ctx;
-    return MLKEM_OK;
-}
-
-struct DevBuf {   // device staging of a host-pointer call; zeroed before it is freed (seeds, keys and shared secrets pass through)
+struct DevBuf {   // device staging of a host-pointer primitive call; zeroed before it is freed
     void* p = nullptr;
     size_t size = 0;
     ~DevBuf() {
@@ -466,107 +490,17 @@ struct DevBuf {   // device staging of a host-pointer call; zeroed before it is 
     template <class T> T* as() { return static_cast<T*>(p); }
 };
 
-}   // namespace
-
-extern "C" {
-
-// The host-pointer KEM calls are the streaming front-end with its default chunking: one cached slot for small batches
-// (no allocation per call after the first), two double-buffered slots beyond one chunk.
-int mlkem_keygen(int set, size_t n, const uint8_t* d, const uint8_t* z, uint8_t* ek, uint8_t* dk) {
-    return mlkem_keygen_stream(set, n, d, z, ek, dk, 0);
-}
-int mlkem_encaps(int set, size_t n, const uint8_t* ek, const uint8_t* m, uint8_t* c, uint8_t* K) {
-    return mlkem_encaps_stream(set, n, ek, m, c, K, 0);
-}
-int mlkem_decaps(int set, size_t n, const uint8_t* dk, const uint8_t* c, uint8_t* K, int32_t* status) {
-    if (status || n == 0) return mlkem_decaps_stream(set, n, dk, c, K, status, 0);
-    std::vector<int32_t> st(n);   // the caller did not ask for the hash-check codes; K does not depend on them
-    return mlkem_decaps_stream(set, n, dk, c, K, st.data(), 0);
-}
-
-static int host_ntt(bool inverse, size_t n, const uint16_t* in, uint16_t* out) {
-    if (n && (!in || !out)) return MLKEM_ERR_ARG;
-    std::lock_guard<std::mutex> lock(g_host_mu);
-    mlkem_ctx* ctx;
-    DeviceGuard guard;
-    int rc = host_ctx(&ctx, guard);
-    if (rc) return rc;
-    if (n == 0) return MLKEM_OK;
-    DevBuf bi, bo;
-    if ((rc = bi.alloc(n * 512)) || (rc = bo.alloc(n * 512))) return rc;
-    HIP_TRY(hipMemcpy(bi.p, in, n * 512, hipMemcpyHostToDevice));
-    rc = inverse ? mlkem_intt_dev(ctx, n, bi.as<uint16_t>(), bo.as<uint16_t>(), nullptr)
-                 : mlkem_ntt_dev(ctx, n, bi.as<uint16_t>(), bo.as<uint16_t>(), nullptr);
-    if (rc) return rc;
-    HIP_TRY(hipMemcpy(out, bo.p, n * 512, hipMemcpyDeviceToHost));
-    return MLKEM_OK;
-}
-int mlkem_ntt(size_t n, const uint16_t* f, uint16_t* fh) { return host_ntt(false, n, f, fh); }
-int mlkem_intt(size_t n, const uint16_t* fh, uint16_t* f) { return host_ntt(true, n, fh, f); }
-
-int mlkem_sample_ntt(size_t n, const uint8_t* seeds34, uint16_t* a_hat) {
-    if (n && (!seeds34 || !a_hat)) return MLKEM_ERR_ARG;
-    std::lock_guard<std::mutex> lock(g_host_mu);
-    mlkem_ctx* ctx;
-    DeviceGuard guard;
-    int rc = host_ctx(&ctx, guard);
-    if (rc) return rc;
-    if (n == 0) return MLKEM_OK;
-    DevBuf bi, bo;
-    if ((rc = bi.alloc(n * 34)) || (rc = bo.alloc(n * 512))) return rc;
-    HIP_TRY(hipMemcpy(bi.p, seeds34, n * 34, hipMemcpyHostToDevice));
-    if ((rc = mlkem_sample_ntt_dev(ctx, n, bi.as<uint8_t>(), bo.as<uint16_t>(), nullptr))) return rc;
-    HIP_TRY(hipMemcpy(a_hat, bo.p, n * 512, hipMemcpyDeviceToHost));
-    return MLKEM_OK;
-}
-int mlkem_sample_cbd(int eta, size_t n, const uint8_t* bytes, uint16_t* f) {
-    if ((eta != 2 && eta != 3) || (n && (!bytes || !f))) return MLKEM_ERR_ARG;
-    std::lock_guard<std::mutex> lock(g_host_mu);
-    mlkem_ctx* ctx;
-    DeviceGuard guard;
-    int rc = host_ctx(&ctx, guard);
-    if (rc) return rc;
-    if (n == 0) return MLKEM_OK;
-    DevBuf bi, bo;
-    if ((rc = bi.alloc(n * 64 * (size_t)eta)) || (rc = bo.alloc(n * 512))) return rc;
-    HIP_TRY(hipMemcpy(bi.p, bytes, n * 64 * (size_t)eta, hipMemcpyHostToDevice));
-    if ((rc = mlkem_sample_cbd_dev(ctx, eta, n, bi.as<uint8_t>(), bo.as<uint16_t>(), nullptr))) return rc;
-    HIP_TRY(hipMemcpy(f, bo.p, n * 512, hipMemcpyDeviceToHost));
-    return MLKEM_OK;
-}
-
-int mlkem_keccak_sponge(unsigned rate, size_t n, const uint8_t* padded, unsigned nblocks, uint8_t* out, unsigned outlen) {
-    if (n && (!padded || !out)) return MLKEM_ERR_ARG;
-    std::lock_guard<std::mutex> lock(g_host_mu);
-    mlkem_ctx* ctx;
-    DeviceGuard guard;
-    int rc = host_ctx(&ctx, guard);
-    if (rc) return rc;
-    if (n == 0) return MLKEM_OK;
-    const size_t in_bytes = n * (size_t)nblocks * rate, ostride = ((size_t)outlen + 3) & ~(size_t)3;
-    DevBuf bi, bo;
-    if ((rc = bi.alloc(in_bytes)) || (rc = bo.alloc(n * ostride))) return rc;
-    HIP_TRY(hipMemcpy(bi.p, padded, in_bytes, hipMemcpyHostToDevice));
-    rc = mlkem_keccak_sponge_dev(ctx, rate, n, bi.as<uint8_t>(), nblocks, bo.as<uint8_t>(), outlen, ostride, nullptr);
-    if (rc) return rc;
-    std::vector<uint8_t> tmp(n * ostride);
-    HIP_TRY(hipMemcpy(tmp.data(), bo.p, n * ostride, hipMemcpyDeviceToHost));
-    for (size_t i = 0; i < n; i++) memcpy(out + i * outlen, tmp.data() + i * ostride, outlen);
-    return MLKEM_OK;
-}
-
-}   // extern "C"
-
-// ---- streaming front-end for HOST-resident batches ---------------------------------------------
-// Two slots, each with its own stream, engine context, device buffers and PINNED staging buffers.  Chunk i uses slot
-// i & 1: while slot A's H2D copy / kernels / D2H copy run, the host drains slot B's previous outputs into the caller's
-// memory and fills its staging buffers with the next inputs.  The rate is bounded by PCIe.
-namespace {
-
+// ---- streaming engine: host-resident batches of any size ----------------------------------------
+// Three in-order streams (H2D copies / kernels / D2H copies) and NSETS sets of device buffers ordered by events:
+//   kernels(i) wait for H2D(i) and for D2H(i - NSETS) (output buffers free); D2H(i) waits for kernels(i);
+//   H2D(i) waits for kernels(i - NSETS) (input buffers free).
+// PCIe is full duplex, so in steady state H2D(i+1), kernels(i) and D2H(i-1) overlap.  A caller buffer that is pinned
+// (hipHostMalloc / hipHostRegister / mlkem_host_register) is used by the DMA engines directly and the host never blocks
+// between chunks; a pageable buffer goes through the set's pinned staging buffer with threaded memcpy.
 struct Span { const void* in; void* out; size_t bytes; };   // per-item bytes; exactly one of in/out is set
 
-// The staging copies between the caller's pageable memory and the pinned buffers are the bottleneck of the streaming
-// front-end (a single memcpy thread moves ~10 GB/s, PCIe Gen5 x16 ~50): large copies are split over a few threads.
+constexpr int NSETS = 3;
+
 void par_memcpy(void* dst, const void* src, size_t bytes) {
     constexpr size_t MIN_PER_THREAD = (size_t)2 << 20;
     unsigned hw = std::thread::hardware_concurrency();
@@ -587,145 +521,382 @@ void par_memcpy(void* dst, const void* src, size_t bytes) {
     for (auto& x : th) x.join();
 }
 
-// A slot = stream + engine context + per-span device and pinned staging buffers.  The two slots live in a process-wide
-// cache and are reused by later calls (pinning host memory costs about as much as copying it once, so per-call
-// allocation used to dominate large chunks); buffers only grow, the context is recreated when the chunk size or the
-// device changes.  mlkem_stream_release() zeroes and frees everything.
-struct StageBuf {
-    void* dev = nullptr;
-    void* pin = nullptr;
-    size_t cap = 0;
-};
-struct StreamSlot {
-    hipStream_t st = nullptr;
-    mlkem_ctx* ctx = nullptr;
-    size_t ctx_chunk = 0;
-    int device = -1;
-    std::vector<StageBuf> buf;
-    size_t pending = 0, pending_off = 0;   // items whose outputs still sit in the pinned buffers
-};
-std::mutex g_stream_mu;
-StreamSlot g_slot[2];
-
-void slot_release(StreamSlot& s) {
-    if (s.st) (void)hipStreamSynchronize(s.st);
-    for (StageBuf& b : s.buf) {   // staging buffers carry seeds / keys / shared secrets: zero, then free
-        if (b.dev) { (void)hipMemset(b.dev, 0, b.cap); (void)hipFree(b.dev); }
-        if (b.pin) { explicit_bzero(b.pin, b.cap); (void)hipHostFree(b.pin); }
+// is [p, p + bytes) host memory the DMA engines can address directly (pinned or registered)?
+bool host_pinned(const void* p) {
+    hipPointerAttribute_t a;
+    memset(&a, 0, sizeof a);
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+        (void)hipGetLastError();   // pageable memory: "invalid value" on this runtime; not an error of the call
+        return false;
     }
-    s.buf.clear();
-    if (s.ctx) mlkem_ctx_destroy(s.ctx);
-    if (s.st) (void)hipStreamDestroy(s.st);
-    s = StreamSlot();
+    return a.type == hipMemoryTypeHost;
 }
 
-int slot_prepare(StreamSlot& s, int dev, size_t chunk, const std::vector<Span>& spans) {
-    if (s.device != dev && s.device >= 0) slot_release(s);
-    s.device = dev;
-    if (!s.st && !hip_ok(hipStreamCreateWithFlags(&s.st, hipStreamNonBlocking), "hipStreamCreate")) return MLKEM_ERR_NO_DEVICE;
-    if (!s.ctx || s.ctx_chunk < chunk) {   // a context serves any batch size; its chunk capacity only grows
-        if (s.ctx) mlkem_ctx_destroy(s.ctx);
-        s.ctx = nullptr;
-        int rc = mlkem_ctx_create(&s.ctx, dev, chunk);
+struct StageBuf {
+    void* dev = nullptr;
+    void* pin = nullptr;   // allocated on first use by a pageable caller buffer
+    size_t cap = 0;
+};
+struct BufSet {
+    std::vector<StageBuf> buf;
+    hipEvent_t evH = nullptr, evK = nullptr, evD = nullptr;
+    size_t pending = 0, pending_off = 0;   // items whose outputs have not been handed to the caller yet
+};
+struct StreamEngine {
+    std::mutex mu;
+    int device = -1;
+    hipStream_t h2d = nullptr, k = nullptr, d2h = nullptr;
+    mlkem_ctx* ctx = nullptr;
+    size_t ctx_chunk = 0;
+    BufSet set[NSETS];
+};
+
+void stage_free(StageBuf& b) {   // staging buffers carry seeds / keys / shared secrets: zero, then free
+    if (b.dev) { (void)hipMemset(b.dev, 0, b.cap); (void)hipFree(b.dev); b.dev = nullptr; }
+    if (b.pin) { explicit_bzero(b.pin, b.cap); (void)hipHostFree(b.pin); b.pin = nullptr; }
+    b.cap = 0;
+}
+
+void engine_release(StreamEngine& e) {   // caller holds e.mu (or owns e exclusively)
+    if (e.device < 0) return;
+    DeviceGuard g;
+    (void)g.enter(e.device);
+    for (hipStream_t s : {e.h2d, e.k, e.d2h})
+        if (s) (void)hipStreamSynchronize(s);
+    for (BufSet& s : e.set) {
+        for (StageBuf& b : s.buf) stage_free(b);
+        s.buf.clear();
+        for (hipEvent_t* ev : {&s.evH, &s.evK, &s.evD})
+            if (*ev) { (void)hipEventDestroy(*ev); *ev = nullptr; }
+        s.pending = 0;
+    }
+    if (e.ctx) mlkem_ctx_destroy(e.ctx);
+    e.ctx = nullptr;
+    e.ctx_chunk = 0;
+    for (hipStream_t* s : {&e.h2d, &e.k, &e.d2h})
+        if (*s) { (void)hipStreamDestroy(*s); *s = nullptr; }
+    e.device = -1;
+}
+
+int engine_prepare(StreamEngine& e, int dev, size_t chunk, const std::vector<Span>& spans, const std::vector<char>& staged, int nsets) {
+    if (e.device >= 0 && e.device != dev) engine_release(e);
+    e.device = dev;
+    for (hipStream_t* s : {&e.h2d, &e.k, &e.d2h})
+        if (!*s && !hip_ok(hipStreamCreateWithFlags(s, hipStreamNonBlocking), "hipStreamCreate")) return MLKEM_ERR_NO_DEVICE;
+    if (!e.ctx || e.ctx_chunk < chunk) {   // a context serves any batch size; its chunk capacity only grows
+        if (e.ctx) {
+            (void)hipStreamSynchronize(e.k);
+            mlkem_ctx_destroy(e.ctx);
+        }
+        e.ctx = nullptr;
+        int rc = mlkem_ctx_create(&e.ctx, dev, chunk);
         if (rc) return rc;
-        s.ctx_chunk = chunk;
+        e.ctx_chunk = chunk;
     }
-    if (s.buf.size() < spans.size()) s.buf.resize(spans.size());
-    for (size_t j = 0; j < spans.size(); j++) {
-        StageBuf& b = s.buf[j];
-        const size_t need = chunk * spans[j].bytes;
-        if (b.cap >= need) continue;
-        if (b.dev) { (void)hipMemset(b.dev, 0, b.cap); (void)hipFree(b.dev); b.dev = nullptr; }
-        if (b.pin) { explicit_bzero(b.pin, b.cap); (void)hipHostFree(b.pin); b.pin = nullptr; }
-        b.cap = 0;
-        if (!hip_ok(hipMalloc(&b.dev, need), "hipMalloc")) return MLKEM_ERR_ALLOC;
-        if (!hip_ok(hipHostMalloc(&b.pin, need, hipHostMallocDefault), "hipHostMalloc")) return MLKEM_ERR_ALLOC;
-        b.cap = need;
+    for (int k = 0; k < nsets; k++) {
+        BufSet& s = e.set[k];
+        for (hipEvent_t* ev : {&s.evH, &s.evK, &s.evD})
+            if (!*ev && !hip_ok(hipEventCreateWithFlags(ev, hipEventDisableTiming), "hipEventCreate")) return MLKEM_ERR_NO_DEVICE;
+        if (s.buf.size() < spans.size()) s.buf.resize(spans.size());
+        for (size_t j = 0; j < spans.size(); j++) {
+            StageBuf& b = s.buf[j];
+            const size_t need = chunk * spans[j].bytes;
+            if (b.cap < need) {
+                for (hipStream_t st : {e.h2d, e.k, e.d2h}) (void)hipStreamSynchronize(st);
+                stage_free(b);
+                if (!hip_ok(hipMalloc(&b.dev, need), "hipMalloc")) return MLKEM_ERR_ALLOC;
+                b.cap = need;
+            }
+            if (staged[j] && !b.pin && !hip_ok(hipHostMalloc(&b.pin, b.cap, hipHostMallocDefault), "hipHostMalloc")) return MLKEM_ERR_ALLOC;
+        }
+        s.pending = 0;
     }
-    s.pending = 0;
     return MLKEM_OK;
 }
 
+size_t default_stream_chunk() {
+    if (const char* e = getenv("MLKEM_STREAM_CHUNK_ITEMS")) {
+        long long v = atoll(e);
+        if (v > 0) return (size_t)v;
+    }
+    return (size_t)1 << 14;   // measured best on MI355X (tools/stream_bench.py)
+}
+
+// runs on the calling thread; the engine's device must be current
 template <class Launch>
-int stream_op(size_t n, size_t chunk, const std::vector<Span>& spans, Launch launch) {
+int stream_op(StreamEngine& e, size_t n, size_t chunk, const std::vector<Span>& spans, Launch launch) {
     if (n == 0) return MLKEM_OK;
-    if (chunk == 0) chunk = (size_t)1 << 14;   // measured best on MI355X (tools/stream_bench.py)
+    if (chunk == 0) chunk = default_stream_chunk();
     if (chunk > n) chunk = n;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return MLKEM_ERR_NO_DEVICE;
-    std::lock_guard<std::mutex> lock(g_stream_mu);
-    const int nslots = n > chunk ? 2 : 1;
-    int rc = MLKEM_OK;
-    for (int k = 0; k < nslots && rc == MLKEM_OK; k++) rc = slot_prepare(g_slot[k], dev, chunk, spans);
-    auto drain = [&](StreamSlot& s) -> int {   // wait for the slot and hand its outputs to the caller
+    std::lock_guard<std::mutex> lock(e.mu);
+    const size_t nchunks = (n + chunk - 1) / chunk;
+    const int nsets = nchunks < (size_t)NSETS ? (int)nchunks : NSETS;
+    std::vector<char> staged(spans.size());
+    for (size_t j = 0; j < spans.size(); j++) staged[j] = !host_pinned(spans[j].in ? spans[j].in : spans[j].out);
+    int rc = engine_prepare(e, dev, chunk, spans, staged, nsets);
+    auto drain = [&](BufSet& s) -> int {   // wait for the set's D2H copies and hand staged outputs to the caller
         if (!s.pending) return MLKEM_OK;
-        if (!hip_ok(hipStreamSynchronize(s.st), "hipStreamSynchronize")) return MLKEM_ERR_NO_DEVICE;
+        if (!hip_ok(hipEventSynchronize(s.evD), "hipEventSynchronize")) return MLKEM_ERR_NO_DEVICE;
         for (size_t j = 0; j < spans.size(); j++)
-            if (spans[j].out) par_memcpy(static_cast<uint8_t*>(spans[j].out) + s.pending_off * spans[j].bytes, s.buf[j].pin, s.pending * spans[j].bytes);
+            if (spans[j].out && staged[j])
+                par_memcpy(static_cast<uint8_t*>(spans[j].out) + s.pending_off * spans[j].bytes, s.buf[j].pin, s.pending * spans[j].bytes);
         s.pending = 0;
         return MLKEM_OK;
     };
-    size_t i = 0;
+    bool any_staged = false;
+    for (char c : staged) any_staged = any_staged || c;
     std::vector<void*> devp(spans.size());
+    size_t i = 0;
     for (size_t off = 0; off < n && rc == MLKEM_OK; off += chunk, i++) {
-        StreamSlot& s = g_slot[i % nslots];
+        BufSet& s = e.set[i % nsets];
         const size_t cnt = n - off < chunk ? n - off : chunk;
-        if ((rc = drain(s)) != MLKEM_OK) break;
+        if (any_staged && (rc = drain(s)) != MLKEM_OK) break;        // frees the set's pinned buffers (and implies its H2D is done)
+        (void)hipStreamWaitEvent(e.h2d, s.evK, 0);                   // the set's previous kernels have consumed its inputs
         for (size_t j = 0; j < spans.size() && rc == MLKEM_OK; j++) {
             devp[j] = s.buf[j].dev;
-            if (spans[j].in) {
-                par_memcpy(s.buf[j].pin, static_cast<const uint8_t*>(spans[j].in) + off * spans[j].bytes, cnt * spans[j].bytes);
-                if (!hip_ok(hipMemcpyAsync(s.buf[j].dev, s.buf[j].pin, cnt * spans[j].bytes, hipMemcpyHostToDevice, s.st), "H2D")) rc = MLKEM_ERR_NO_DEVICE;
+            if (!spans[j].in) continue;
+            const uint8_t* src = static_cast<const uint8_t*>(spans[j].in) + off * spans[j].bytes;
+            if (staged[j]) {
+                par_memcpy(s.buf[j].pin, src, cnt * spans[j].bytes);
+                src = static_cast<const uint8_t*>(s.buf[j].pin);
             }
+            if (!hip_ok(hipMemcpyAsync(s.buf[j].dev, src, cnt * spans[j].bytes, hipMemcpyHostToDevice, e.h2d), "H2D")) rc = MLKEM_ERR_NO_DEVICE;
         }
-        if (rc == MLKEM_OK) rc = launch(s.ctx, cnt, devp, s.st);
-        for (size_t j = 0; j < spans.size() && rc == MLKEM_OK; j++)
-            if (spans[j].out && !hip_ok(hipMemcpyAsync(s.buf[j].pin, s.buf[j].dev, cnt * spans[j].bytes, hipMemcpyDeviceToHost, s.st), "D2H")) rc = MLKEM_ERR_NO_DEVICE;
+        if (rc != MLKEM_OK) break;
+        (void)hipEventRecord(s.evH, e.h2d);
+        (void)hipStreamWaitEvent(e.k, s.evH, 0);
+        (void)hipStreamWaitEvent(e.k, s.evD, 0);                     // the set's previous outputs have left the device
+        rc = launch(e.ctx, cnt, devp, e.k);
+        if (rc != MLKEM_OK) break;
+        (void)hipEventRecord(s.evK, e.k);
+        (void)hipStreamWaitEvent(e.d2h, s.evK, 0);
+        for (size_t j = 0; j < spans.size() && rc == MLKEM_OK; j++) {
+            if (!spans[j].out) continue;
+            void* dst = staged[j] ? s.buf[j].pin : static_cast<void*>(static_cast<uint8_t*>(spans[j].out) + off * spans[j].bytes);
+            if (!hip_ok(hipMemcpyAsync(dst, s.buf[j].dev, cnt * spans[j].bytes, hipMemcpyDeviceToHost, e.d2h), "D2H")) rc = MLKEM_ERR_NO_DEVICE;
+        }
+        (void)hipEventRecord(s.evD, e.d2h);
         s.pending = cnt;
         s.pending_off = off;
     }
-    for (int k = 0; k < nslots && rc == MLKEM_OK; k++) rc = drain(g_slot[k]);
-    if (rc != MLKEM_OK) {   // leave nothing half-done behind
-        for (int k = 0; k < 2; k++) slot_release(g_slot[k]);
-    }
+    // hand over in issue order: the oldest pending set first
+    for (int k = 0; k < nsets && rc == MLKEM_OK; k++) rc = drain(e.set[(i + k) % nsets]);
+    if (rc == MLKEM_OK && !hip_ok(hipStreamSynchronize(e.d2h), "hipStreamSynchronize")) rc = MLKEM_ERR_NO_DEVICE;
+    if (rc != MLKEM_OK) engine_release(e);   // leave nothing half-done behind
     return rc;
+}
+
+struct HostState {
+    std::mutex mu;              // serialises the host-pointer primitives of one device
+    int device = 0;
+    mlkem_ctx* ctx = nullptr;   // chunk capacity 1: the primitives use no scratch
+    StreamEngine eng;
+};
+std::mutex g_reg_mu;
+std::map<int, HostState*> g_host;
+
+HostState* host_state_current(int* dev_out = nullptr) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    if (dev_out) *dev_out = dev;
+    std::lock_guard<std::mutex> lock(g_reg_mu);
+    HostState*& hs = g_host[dev];
+    if (!hs) {
+        hs = new (std::nothrow) HostState();
+        if (hs) hs->device = dev;
+    }
+    return hs;
+}
+// caller holds hs->mu
+int host_ctx(HostState* hs, mlkem_ctx** out) {
+    if (!hs->ctx) {
+        int rc = mlkem_ctx_create(&hs->ctx, hs->device, 1);
+        if (rc) return rc;
+    }
+    *out = hs->ctx;
+    return MLKEM_OK;
+}
+
+// the three KEM operations as (spans, launch) pairs for stream_op
+int kem_stream(StreamEngine& e, int op, int set, size_t n, const void* a, const void* b, void* x, void* y, size_t chunk) {
+    ParamSet p;
+    if (!param_set(set, p)) return MLKEM_ERR_PARAM_SET;
+    if (n && (!a || !b || !x || !y)) return MLKEM_ERR_ARG;
+    if (op == 0) {   // keygen: d, z -> ek, dk
+        std::vector<Span> sp = {{a, nullptr, 32}, {b, nullptr, 32}, {nullptr, x, p.ek_len}, {nullptr, y, p.dk_len}};
+        return stream_op(e, n, chunk, sp, [&](mlkem_ctx* ctx, size_t cnt, const std::vector<void*>& v, hipStream_t st) {
+            return mlkem_keygen_dev(ctx, set, cnt, (const uint8_t*)v[0], (const uint8_t*)v[1], (uint8_t*)v[2], (uint8_t*)v[3], st);
+        });
+    }
+    if (op == 1) {   // encaps: ek, m -> c, K
+        std::vector<Span> sp = {{a, nullptr, p.ek_len}, {b, nullptr, 32}, {nullptr, x, p.c_len}, {nullptr, y, 32}};
+        return stream_op(e, n, chunk, sp, [&](mlkem_ctx* ctx, size_t cnt, const std::vector<void*>& v, hipStream_t st) {
+            return mlkem_encaps_dev(ctx, set, cnt, (const uint8_t*)v[0], (const uint8_t*)v[1], (uint8_t*)v[2], (uint8_t*)v[3], st);
+        });
+    }
+    // decaps: dk, c -> K, status
+    std::vector<Span> sp = {{a, nullptr, p.dk_len}, {b, nullptr, p.c_len}, {nullptr, x, 32}, {nullptr, y, 4}};
+    return stream_op(e, n, chunk, sp, [&](mlkem_ctx* ctx, size_t cnt, const std::vector<void*>& v, hipStream_t st) {
+        return mlkem_decaps_dev(ctx, set, cnt, (const uint8_t*)v[0], (const uint8_t*)v[1], (uint8_t*)v[2], (int32_t*)v[3], st);
+    });
+}
+
+int kem_stream_current(int op, int set, size_t n, const void* a, const void* b, void* x, void* y, size_t chunk) {
+    HostState* hs = host_state_current();
+    if (!hs) return MLKEM_ERR_NO_DEVICE;
+    return kem_stream(hs->eng, op, set, n, a, b, x, y, chunk);
 }
 
 }   // namespace
 
 extern "C" {
 
-void mlkem_stream_release(void) {
-    std::lock_guard<std::mutex> lock(g_stream_mu);
-    for (int k = 0; k < 2; k++) slot_release(g_slot[k]);
+// The host-pointer KEM calls are the streaming front-end with its default chunking: the engine of the current device is
+// cached between calls (no allocation per call after the first).
+int mlkem_keygen(int set, size_t n, const uint8_t* d, const uint8_t* z, uint8_t* ek, uint8_t* dk) {
+    return mlkem_keygen_stream(set, n, d, z, ek, dk, 0);
 }
-
+int mlkem_encaps(int set, size_t n, const uint8_t* ek, const uint8_t* m, uint8_t* c, uint8_t* K) {
+    return mlkem_encaps_stream(set, n, ek, m, c, K, 0);
+}
+int mlkem_decaps(int set, size_t n, const uint8_t* dk, const uint8_t* c, uint8_t* K, int32_t* status) {
+    if (status || n == 0) return mlkem_decaps_stream(set, n, dk, c, K, status, 0);
+    std::vector<int32_t> st(n);   // the caller did not ask for the hash-check codes; K does not depend on them
+    return mlkem_decaps_stream(set, n, dk, c, K, st.data(), 0);
+}
 int mlkem_keygen_stream(int set, size_t n, const uint8_t* d, const uint8_t* z, uint8_t* ek, uint8_t* dk, size_t chunk_items) {
-    ParamSet p;
-    if (!param_set(set, p)) return MLKEM_ERR_PARAM_SET;
-    if (n && (!d || !z || !ek || !dk)) return MLKEM_ERR_ARG;
-    std::vector<Span> sp = {{d, nullptr, 32}, {z, nullptr, 32}, {nullptr, ek, p.ek_len}, {nullptr, dk, p.dk_len}};
-    return stream_op(n, chunk_items, sp, [&](mlkem_ctx* ctx, size_t cnt, const std::vector<void*>& b, hipStream_t st) {
-        return mlkem_keygen_dev(ctx, set, cnt, (const uint8_t*)b[0], (const uint8_t*)b[1], (uint8_t*)b[2], (uint8_t*)b[3], st);
-    });
+    return kem_stream_current(0, set, n, d, z, ek, dk, chunk_items);
 }
 int mlkem_encaps_stream(int set, size_t n, const uint8_t* ek, const uint8_t* m, uint8_t* c, uint8_t* K, size_t chunk_items) {
-    ParamSet p;
-    if (!param_set(set, p)) return MLKEM_ERR_PARAM_SET;
-    if (n && (!ek || !m || !c || !K)) return MLKEM_ERR_ARG;
-    std::vector<Span> sp = {{ek, nullptr, p.ek_len}, {m, nullptr, 32}, {nullptr, c, p.c_len}, {nullptr, K, 32}};
-    return stream_op(n, chunk_items, sp, [&](mlkem_ctx* ctx, size_t cnt, const std::vector<void*>& b, hipStream_t st) {
-        return mlkem_encaps_dev(ctx, set, cnt, (const uint8_t*)b[0], (const uint8_t*)b[1], (uint8_t*)b[2], (uint8_t*)b[3], st);
-    });
+    return kem_stream_current(1, set, n, ek, m, c, K, chunk_items);
 }
 int mlkem_decaps_stream(int set, size_t n, const uint8_t* dk, const uint8_t* c, uint8_t* K, int32_t* status, size_t chunk_items) {
-    ParamSet p;
-    if (!param_set(set, p)) return MLKEM_ERR_PARAM_SET;
-    if (n && (!dk || !c || !K || !status)) return MLKEM_ERR_ARG;
-    std::vector<Span> sp = {{dk, nullptr, p.dk_len}, {c, nullptr, p.c_len}, {nullptr, K, 32}, {nullptr, status, 4}};
-    return stream_op(n, chunk_items, sp, [&](mlkem_ctx* ctx, size_t cnt, const std::vector<void*>& b, hipStream_t st) {
-        return mlkem_decaps_dev(ctx, set, cnt, (const uint8_t*)b[0], (const uint8_t*)b[1], (uint8_t*)b[2], (int32_t*)b[3], st);
-    });
+    return kem_stream_current(2, set, n, dk, c, K, status, chunk_items);
+}
+
+// pins caller memory so that the streaming calls hand it to the DMA engines directly (no staging copy)
+int mlkem_host_register(void* p, size_t bytes) {
+    if (!p || !bytes) return MLKEM_ERR_ARG;
+    return hip_ok(hipHostRegister(p, bytes, hipHostRegisterPortable), "hipHostRegister") ? MLKEM_OK : MLKEM_ERR_ALLOC;
+}
+int mlkem_host_unregister(void* p) {
+    if (!p) return MLKEM_ERR_ARG;
+    return hip_ok(hipHostUnregister(p), "hipHostUnregister") ? MLKEM_OK : MLKEM_ERR_ARG;
+}
+
+void mlkem_stream_release(void) {
+    std::lock_guard<std::mutex> lock(g_reg_mu);
+    for (auto& kv : g_host) {
+        std::lock_guard<std::mutex> l2(kv.second->eng.mu);
+        engine_release(kv.second->eng);
+    }
+}
+// wipes and frees everything the host-pointer entry points cached, on every device they were used on
+void mlkem_host_release(void) {
+    std::lock_guard<std::mutex> lock(g_reg_mu);
+    for (auto& kv : g_host) {
+        HostState* hs = kv.second;
+        {
+            std::lock_guard<std::mutex> l2(hs->eng.mu);
+            engine_release(hs->eng);
+        }
+        {
+            std::lock_guard<std::mutex> l3(hs->mu);
+            if (hs->ctx) mlkem_ctx_destroy(hs->ctx);
+            hs->ctx = nullptr;
+        }
+        delete hs;
+    }
+    g_host.clear();
+}
+
+// ---- host-pointer primitives ----------------------------------------------------------------------------------
+#define MLKEM_HOST_PROLOGUE()                                   \
+    HostState* hs = host_state_current();                       \
+    if (!hs) return MLKEM_ERR_NO_DEVICE;                        \
+    std::lock_guard<std::mutex> lock(hs->mu);                   \
+    mlkem_ctx* ctx;                                             \
+    int rc = host_ctx(hs, &ctx);                                \
+    if (rc) return rc;
+
+static int host_ntt(bool inverse, size_t n, const uint16_t* in, uint16_t* out) {
+    if (n && (!in || !out)) return MLKEM_ERR_ARG;
+    MLKEM_HOST_PROLOGUE()
+    if (n == 0) return MLKEM_OK;
+    DevBuf bi, bo;
+    if ((rc = bi.alloc(n * 512)) || (rc = bo.alloc(n * 512))) return rc;
+    HIP_TRY(hipMemcpy(bi.p, in, n * 512, hipMemcpyHostToDevice));
+    rc = inverse ? mlkem_intt_dev(ctx, n, bi.as<uint16_t>(), bo.as<uint16_t>(), nullptr)
+                 : mlkem_ntt_dev(ctx, n, bi.as<uint16_t>(), bo.as<uint16_t>(), nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(out, bo.p, n * 512, hipMemcpyDeviceToHost));
+    return MLKEM_OK;
+}
+int mlkem_ntt(size_t n, const uint16_t* f, uint16_t* fh) { return host_ntt(false, n, f, fh); }
+int mlkem_intt(size_t n, const uint16_t* fh, uint16_t* f) { return host_ntt(true, n, fh, f); }
+
+int mlkem_sample_ntt(size_t n, const uint8_t* seeds34, uint16_t* a_hat) {
+    if (n && (!seeds34 || !a_hat)) return MLKEM_ERR_ARG;
+    MLKEM_HOST_PROLOGUE()
+    if (n == 0) return MLKEM_OK;
+    DevBuf bi, bo;
+    if ((rc = bi.alloc(n * 34)) || (rc = bo.alloc(n * 512))) return rc;
+    HIP_TRY(hipMemcpy(bi.p, seeds34, n * 34, hipMemcpyHostToDevice));
+    if ((rc = mlkem_sample_ntt_dev(ctx, n, bi.as<uint8_t>(), bo.as<uint16_t>(), nullptr))) return rc;
+    HIP_TRY(hipMemcpy(a_hat, bo.p, n * 512, hipMemcpyDeviceToHost));
+    return MLKEM_OK;
+}
+int mlkem_sample_cbd(int eta, size_t n, const uint8_t* bytes, uint16_t* f) {
+    if ((eta != 2 && eta != 3) || (n && (!bytes || !f))) return MLKEM_ERR_ARG;
+    MLKEM_HOST_PROLOGUE()
+    if (n == 0) return MLKEM_OK;
+    DevBuf bi, bo;
+    if ((rc = bi.alloc(n * 64 * (size_t)eta)) || (rc = bo.alloc(n * 512))) return rc;
+    HIP_TRY(hipMemcpy(bi.p, bytes, n * 64 * (size_t)eta, hipMemcpyHostToDevice));
+    if ((rc = mlkem_sample_cbd_dev(ctx, eta, n, bi.as<uint8_t>(), bo.as<uint16_t>(), nullptr))) return rc;
+    HIP_TRY(hipMemcpy(f, bo.p, n * 512, hipMemcpyDeviceToHost));
+    return MLKEM_OK;
+}
+
+int mlkem_keccak_sponge(unsigned rate, size_t n, const uint8_t* padded, unsigned nblocks, uint8_t* out, unsigned outlen) {
+    if (n && (!padded || !out)) return MLKEM_ERR_ARG;
+    MLKEM_HOST_PROLOGUE()
+    if (n == 0) return MLKEM_OK;
+    const size_t in_bytes = n * (size_t)nblocks * rate, ostride = ((size_t)outlen + 3) & ~(size_t)3;
+    DevBuf bi, bo;
+    if ((rc = bi.alloc(in_bytes)) || (rc = bo.alloc(n * ostride))) return rc;
+    HIP_TRY(hipMemcpy(bi.p, padded, in_bytes, hipMemcpyHostToDevice));
+    rc = mlkem_keccak_sponge_dev(ctx, rate, n, bi.as<uint8_t>(), nblocks, bo.as<uint8_t>(), outlen, ostride, nullptr);
+    if (rc) return rc;
+    std::vector<uint8_t> tmp(n * ostride);
+    HIP_TRY(hipMemcpy(tmp.data(), bo.p, n * ostride, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < n; i++) memcpy(out + i * outlen, tmp.data() + i * ostride, outlen);
+    return MLKEM_OK;
+}
+// Compress_d / Decompress_d for any d in 1..12 (ml_kem.c:83-119; d = 12 is the identity there) over n values
+int mlkem_compress(int d, size_t n, const uint16_t* x, uint16_t* y) {
+    if (d < 1 || d > 12 || (n && (!x || !y))) return MLKEM_ERR_ARG;
+    MLKEM_HOST_PROLOGUE()
+    if (n == 0) return MLKEM_OK;
+    DevBuf b;
+    if ((rc = b.alloc(n * 2))) return rc;
+    HIP_TRY(hipMemcpy(b.p, x, n * 2, hipMemcpyHostToDevice));
+    if ((rc = mlkem_compress_dev(ctx, d, n, b.as<uint16_t>(), b.as<uint16_t>(), nullptr))) return rc;
+    HIP_TRY(hipMemcpy(y, b.p, n * 2, hipMemcpyDeviceToHost));
+    return MLKEM_OK;
+}
+int mlkem_decompress(int d, size_t n, const uint16_t* y, uint16_t* x) {
+    if (d < 1 || d > 12 || (n && (!x || !y))) return MLKEM_ERR_ARG;
+    MLKEM_HOST_PROLOGUE()
+    if (n == 0) return MLKEM_OK;
+    DevBuf b;
+    if ((rc = b.alloc(n * 2))) return rc;
+    HIP_TRY(hipMemcpy(b.p, y, n * 2, hipMemcpyHostToDevice));
+    if ((rc = mlkem_decompress_dev(ctx, d, n, b.as<uint16_t>(), b.as<uint16_t>(), nullptr))) return rc;
+    HIP_TRY(hipMemcpy(x, b.p, n * 2, hipMemcpyDeviceToHost));
+    return MLKEM_OK;
 }
 
 // ---- randomised wrappers: KEM_KeyGen / KEM_Encaps semantics at batch scale (ml_kem.c:458-478, :1233, :1257) --
@@ -759,6 +930,192 @@ int mlkem_encaps_random(int set, size_t n, const uint8_t* ek, unsigned ek_len, u
     if (fill_random(m.data(), n * 32)) rc = mlkem_encaps(set, n, ek, m.data(), c, K);
     explicit_bzero(m.data(), m.size());
     return rc;
+}
+
+}   // extern "C"
+
+// ---- in-process sharding over several devices (BASELINE configs[4]) ---------------------------------------
+// An mlkem_multi is a list of MEMBERS, each bound to one HIP device (a device may appear more than once: that is how
+// the sharded path is rehearsed on a single GPU).  A batch of n items is cut into contiguous ranges, member r takes
+// items [start_r, stop_r) = mlkem_shard_range(n, r, R); there is no exchange between members and no collective.
+//   *_multi      host-resident batch: one host thread per member drives that member's streaming engine (own streams,
+//                events, pinned staging) on its device; the call returns when every member has finished
+//   *_multi_dev  device-resident shards: shard r already lives on member r's device; the work is enqueued on the member's
+//                stream and the call returns without synchronising (mlkem_multi_sync waits for all members)
+struct mlkem_multi {
+    struct Member {
+        int device = 0;
+        mlkem_ctx* ctx = nullptr;       // *_multi_dev: created on first use (a context owns ~10 KiB x chunk of HBM)
+        hipStream_t st = nullptr;
+        StreamEngine eng;               // *_multi
+    };
+    std::vector<Member*> mem;
+    size_t chunk = 0;
+};
+
+namespace {
+
+int member_ready(mlkem_multi* mm, mlkem_multi::Member& m) {   // m.device is current
+    if (!m.st && !hip_ok(hipStreamCreateWithFlags(&m.st, hipStreamNonBlocking), "hipStreamCreate")) return MLKEM_ERR_NO_DEVICE;
+    if (!m.ctx) return mlkem_ctx_create(&m.ctx, m.device, mm->chunk);
+    return MLKEM_OK;
+}
+
+// one host thread per member; fn(member index) runs with the member's device current
+template <class Fn>
+int multi_run_threads(mlkem_multi* mm, Fn fn) {
+    const size_t R = mm->mem.size();
+    std::vector<int> rcs(R, MLKEM_OK);
+    std::vector<std::string> errs(R);
+    auto body = [&](size_t r) {
+        if (hipSetDevice(mm->mem[r]->device) != hipSuccess) { rcs[r] = MLKEM_ERR_NO_DEVICE; return; }
+        rcs[r] = fn(r);
+        if (rcs[r]) errs[r] = g_last_hip_error;
+    };
+    std::vector<std::thread> th;
+    for (size_t r = 1; r < R; r++) th.emplace_back(body, r);
+    {
+        DeviceGuard g;
+        if (!g.enter(mm->mem[0]->device)) rcs[0] = MLKEM_ERR_NO_DEVICE;
+        else {
+            rcs[0] = fn(0);
+            if (rcs[0]) errs[0] = g_last_hip_error;
+        }
+    }
+    for (auto& t : th) t.join();
+    for (size_t r = 0; r < R; r++)
+        if (rcs[r]) {
+            g_last_hip_error = errs[r];
+            return rcs[r];
+        }
+    return MLKEM_OK;
+}
+
+}   // namespace
+
+extern "C" {
+
+int mlkem_shard_range(size_t n, int member, int n_members, size_t* start, size_t* stop) {
+    if (n_members <= 0 || member < 0 || member >= n_members || !start || !stop) return MLKEM_ERR_ARG;
+    const size_t base = n / (size_t)n_members, rem = n % (size_t)n_members, r = (size_t)member;
+    *start = r * base + (r < rem ? r : rem);
+    *stop = *start + base + (r < rem ? 1 : 0);
+    return MLKEM_OK;
+}
+
+int mlkem_multi_create(mlkem_multi** out, int n_members, const int* devices, size_t chunk_items) {
+    if (!out) return MLKEM_ERR_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (!hip_ok(hipGetDeviceCount(&ndev), "hipGetDeviceCount") || ndev <= 0) return MLKEM_ERR_NO_DEVICE;
+    if (n_members == 0 && !devices) n_members = ndev;   // every visible device once
+    if (n_members <= 0 || n_members > 1024) return MLKEM_ERR_ARG;
+    for (int r = 0; r < n_members; r++) {
+        const int d = devices ? devices[r] : r;
+        if (d < 0 || d >= ndev) return MLKEM_ERR_ARG;
+    }
+    mlkem_multi* mm = new (std::nothrow) mlkem_multi();
+    if (!mm) return MLKEM_ERR_ALLOC;
+    mm->chunk = chunk_items;
+    for (int r = 0; r < n_members; r++) {
+        auto* m = new (std::nothrow) mlkem_multi::Member();
+        if (!m) { mlkem_multi_destroy(mm); return MLKEM_ERR_ALLOC; }
+        m->device = devices ? devices[r] : r;
+        mm->mem.push_back(m);
+    }
+    *out = mm;
+    return MLKEM_OK;
+}
+
+void mlkem_multi_destroy(mlkem_multi* mm) {
+    if (!mm) return;
+    DeviceGuard g;
+    for (auto* m : mm->mem) {
+        (void)g.enter(m->device);
+        if (m->st) (void)hipStreamSynchronize(m->st);
+        if (m->ctx) mlkem_ctx_destroy(m->ctx);
+        if (m->st) (void)hipStreamDestroy(m->st);
+        engine_release(m->eng);
+        delete m;
+    }
+    delete mm;
+}
+
+int mlkem_multi_members(const mlkem_multi* mm) { return mm ? (int)mm->mem.size() : 0; }
+int mlkem_multi_device(const mlkem_multi* mm, int member) {
+    if (!mm || member < 0 || member >= (int)mm->mem.size()) return MLKEM_ERR_ARG;
+    return mm->mem[member]->device;
+}
+
+// ---- host-resident batch, sharded over the members ------------------------------------------------------------------
+static int multi_host(mlkem_multi* mm, int op, int set, size_t n, const uint8_t* a, const uint8_t* b, uint8_t* x, uint8_t* y,
+                      size_t chunk_items) {
+    ParamSet p;
+    if (!param_set(set, p)) return MLKEM_ERR_PARAM_SET;
+    if (!mm || mm->mem.empty() || (n && (!a || !b || !x || !y))) return MLKEM_ERR_ARG;
+    const size_t la = op == 0 ? 32 : op == 1 ? p.ek_len : p.dk_len, lb = op == 2 ? p.c_len : 32;
+    const size_t lx = op == 0 ? p.ek_len : op == 1 ? p.c_len : 32, ly = op == 0 ? p.dk_len : op == 1 ? 32 : 4;
+    const int R = (int)mm->mem.size();
+    return multi_run_threads(mm, [&](size_t r) -> int {
+        size_t lo, hi;
+        mlkem_shard_range(n, (int)r, R, &lo, &hi);
+        return kem_stream(mm->mem[r]->eng, op, set, hi - lo, a + lo * la, b + lo * lb, x + lo * lx, y + lo * ly, chunk_items);
+    });
+}
+int mlkem_keygen_multi(mlkem_multi* mm, int set, size_t n, const uint8_t* d, const uint8_t* z, uint8_t* ek, uint8_t* dk, size_t chunk_items) {
+    return multi_host(mm, 0, set, n, d, z, ek, dk, chunk_items);
+}
+int mlkem_encaps_multi(mlkem_multi* mm, int set, size_t n, const uint8_t* ek, const uint8_t* m, uint8_t* c, uint8_t* K, size_t chunk_items) {
+    return multi_host(mm, 1, set, n, ek, m, c, K, chunk_items);
+}
+int mlkem_decaps_multi(mlkem_multi* mm, int set, size_t n, const uint8_t* dk, const uint8_t* c, uint8_t* K, int32_t* status, size_t chunk_items) {
+    if (status || n == 0) return multi_host(mm, 2, set, n, dk, c, K, reinterpret_cast<uint8_t*>(status), chunk_items);
+    std::vector<int32_t> st(n);
+    return multi_host(mm, 2, set, n, dk, c, K, reinterpret_cast<uint8_t*>(st.data()), chunk_items);
+}
+
+// ---- device-resident shards ------------------------------------------------------------------------------------------
+// Arrays of length mlkem_multi_members(): shard r (n_shard[r] items) lives on member r's device.  Enqueued from the
+// calling thread (a launch costs microseconds, a shard milliseconds), each member on its own stream; not ordered after
+// any other stream: the inputs must be complete when the call is made.
+static int multi_dev(mlkem_multi* mm, int op, int set, const size_t* n_shard, const uint8_t* const* a, const uint8_t* const* b,
+                     uint8_t* const* x, void* const* y) {
+    ParamSet p;
+    if (!param_set(set, p)) return MLKEM_ERR_PARAM_SET;
+    if (!mm || mm->mem.empty() || !n_shard || !a || !b || !x) return MLKEM_ERR_ARG;
+    DeviceGuard g;
+    int rc = MLKEM_OK;
+    for (size_t r = 0; r < mm->mem.size() && rc == MLKEM_OK; r++) {
+        auto& m = *mm->mem[r];
+        if (!g.enter(m.device)) return MLKEM_ERR_NO_DEVICE;
+        if ((rc = member_ready(mm, m))) break;
+        const size_t n = n_shard[r];
+        if (op == 0) rc = mlkem_keygen_dev(m.ctx, set, n, a[r], b[r], x[r], static_cast<uint8_t*>(y ? y[r] : nullptr), m.st);
+        else if (op == 1) rc = mlkem_encaps_dev(m.ctx, set, n, a[r], b[r], x[r], static_cast<uint8_t*>(y ? y[r] : nullptr), m.st);
+        else rc = mlkem_decaps_dev(m.ctx, set, n, a[r], b[r], x[r], static_cast<int32_t*>(y ? y[r] : nullptr), m.st);
+    }
+    return rc;
+}
+int mlkem_keygen_multi_dev(mlkem_multi* mm, int set, const size_t* n_shard, const uint8_t* const* d, const uint8_t* const* z,
+                           uint8_t* const* ek, uint8_t* const* dk) {
+    return multi_dev(mm, 0, set, n_shard, d, z, ek, reinterpret_cast<void* const*>(dk));
+}
+int mlkem_encaps_multi_dev(mlkem_multi* mm, int set, const size_t* n_shard, const uint8_t* const* ek, const uint8_t* const* m,
+                           uint8_t* const* c, uint8_t* const* K) {
+    return multi_dev(mm, 1, set, n_shard, ek, m, c, reinterpret_cast<void* const*>(K));
+}
+int mlkem_decaps_multi_dev(mlkem_multi* mm, int set, const size_t* n_shard, const uint8_t* const* dk, const uint8_t* const* c,
+                           uint8_t* const* K, int32_t* const* status) {
+    return multi_dev(mm, 2, set, n_shard, dk, c, K, reinterpret_cast<void* const*>(status));
+}
+int mlkem_multi_sync(mlkem_multi* mm) {
+    if (!mm) return MLKEM_ERR_ARG;
+    DeviceGuard g;
+    for (auto* m : mm->mem) {
+        if (!m->st) continue;
+        if (!g.enter(m->device) || !hip_ok(hipStreamSynchronize(m->st), "hipStreamSynchronize")) return MLKEM_ERR_NO_DEVICE;
+    }
+    return MLKEM_OK;
 }
 
 }   // extern "C"

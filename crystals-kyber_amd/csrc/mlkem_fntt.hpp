@@ -63,6 +63,15 @@ __device__ __forceinline__ int fcanon(float x) {
     return (int)r;
 }
 
+// canonical representative in [0, q) as a float, for integer |x| <= 2^20, in three full-rate instructions:
+//   k = floor(x fl(1/q) + 2^-13) = floor(x / q) exactly: the bias exceeds the evaluation error (<= 2 * 315 * 2^-24 < 4e-5)
+//   and is smaller than the distance 1/q = 3.0e-4 of any non-multiple's quotient from the next integer
+//   r = x - k q                  exact
+__device__ __forceinline__ float fcanon_floor(float x) {
+    const float k = __builtin_floorf(__builtin_fmaf(x, F_INVQ, 0.0001220703125f));
+    return __builtin_fmaf(k, -F_Q, x);
+}
+
 // Compress_d (ml_kem.c:83-97) of ANY representative x (integer, |x| <= 4095) without canonicalising it first:
 // round(2^d x / q) mod 2^d is invariant under x -> x + q, and q is odd, so there are no ties.
 //   t  = 2^d x                         exact (|t| < 2^23.1)
@@ -240,15 +249,18 @@ __device__ __forceinline__ void stash_vhat_f(float* vh, float* vg, const float (
 }
 // acc = (acc + a o v) reduced : for 0 <= a <= 4095 (raw 12-bit, F3) and |v|, |acc| <= 1665 the exact sum is
 // <= 1665 + 2 * 4095 * 1665 < 2^24, so the fp32 evaluation is exact and one `fred` per coefficient suffices.
+__device__ __forceinline__ float basemul_term(float acc, float a0, float y0, float a1, float y1) {
+    return fred(__builtin_fmaf(a1, y1, __builtin_fmaf(a0, y0, acc)));   // swept over its whole domain on the device (mlkem_selftest.hpp)
+}
 __device__ __forceinline__ void basemul_acc_f(float (&acc)[4], const float (&a)[4], const float* vh, const float* vg) {
     const int l = lane_id();
     float y[4];
     fx_read4(vh, 4 * l, y);
     const float2 g = *reinterpret_cast<const float2*>(vg + 2 * l);
-    acc[0] = fred(__builtin_fmaf(a[1], g.x, __builtin_fmaf(a[0], y[0], acc[0])));
-    acc[1] = fred(__builtin_fmaf(a[1], y[0], __builtin_fmaf(a[0], y[1], acc[1])));
-    acc[2] = fred(__builtin_fmaf(a[3], g.y, __builtin_fmaf(a[2], y[2], acc[2])));
-    acc[3] = fred(__builtin_fmaf(a[3], y[2], __builtin_fmaf(a[2], y[3], acc[3])));
+    acc[0] = basemul_term(acc[0], a[0], y[0], a[1], g.x);
+    acc[1] = basemul_term(acc[1], a[0], y[1], a[1], y[0]);
+    acc[2] = basemul_term(acc[2], a[2], y[2], a[3], g.y);
+    acc[3] = basemul_term(acc[3], a[2], y[3], a[3], y[2]);
 }
 
 // uint16 polynomial in HBM (natural order) -> 4 floats per lane (values 0..65535 -> exact)

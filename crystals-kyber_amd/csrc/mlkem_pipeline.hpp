@@ -461,6 +461,16 @@ inline int codec_launch(stream_t st, bool encode, int d, size_t n, const void* i
     }
 #undef MLKEM_CODEC_CASE
 }
+// Compress_d / Decompress_d value by value, any d in 1..12 (in-place allowed)
+inline int compress_values_launch(stream_t st, bool decompress, int d, size_t n, const uint16_t* in, uint16_t* out) {
+    if (d < 1 || d > 12) return -1;
+    size_t grid = ceil_div(ceil_div(n, 8), 256);
+    if (grid > 256 * 8) grid = 256 * 8;
+    if (grid == 0) return 0;
+    if (decompress) launch("k_decompress_values", k_compress_values<true>, grid, 256u, st, n, d, in, out);
+    else launch("k_compress_values", k_compress_values<false>, grid, 256u, st, n, d, in, out);
+    return 0;
+}
 // stand-alone SampleNTT over explicit 34-byte seeds: the general kernel in direct mode
 inline void sample_ntt_launch(stream_t st, size_t n, const uint8_t* seeds34, uint16_t* out) {
     SampleArgs a{};

@@ -131,6 +131,11 @@ int mlkem_compress_encode_dev(mlkem_ctx* ctx, int d, size_t n, const uint16_t* f
 /* replaces Decompress(ByteDecode(B, d), d) ml_kem.c:153-177 + :104-119 ; d = 12 : the raw 12-bit values, NOT reduced mod q
  *          (ml_kem.c:170) */
 int mlkem_decode_decompress_dev(mlkem_ctx* ctx, int d, size_t n, const uint8_t* bytes, uint16_t* f, void* stream);
+/* replaces Compress(x, d) / Decompress(y, d)  ml_kem.c:83-97 / :104-119, value by value, for ANY d in 1..12 and any 12-bit
+ * input (taken mod 2^12 like the reference's `union integer.t`; d = 12 is the identity; the rounded quotient wraps at 12
+ * bits like the reference's field does).  n uint16 values in, n out; in-place allowed. */
+int mlkem_compress_dev(mlkem_ctx* ctx, int d, size_t n, const uint16_t* x, uint16_t* y, void* stream);
+int mlkem_decompress_dev(mlkem_ctx* ctx, int d, size_t n, const uint16_t* y, uint16_t* x, void* stream);
 /* replaces SampleNTT(B)        ml_kem.c:189-245 ; seeds : n x 34 bytes (packed) */
 int mlkem_sample_ntt_dev(mlkem_ctx* ctx, size_t n, const uint8_t* seeds34, uint16_t* a_hat, void* stream);
 /* replaces SamplePolyCBD(B, eta) ml_kem.c:253-275 ; bytes : n x 64*eta */
@@ -149,6 +154,19 @@ int mlkem_keccak_sponge_dev(mlkem_ctx* ctx, unsigned rate, size_t n, const uint8
 /* host helper, no device work: message bits (one per byte) + suffix ("01" hash / "1111" XOF: sha3.c:408-436) + pad10*1
  * (sha3.c:226-240) -> whole rate blocks in `padded`; returns the number of blocks or a negative error */
 int mlkem_sha3_pad_bits(const uint8_t* msg_bits, size_t nbits, int xof, unsigned rate, uint8_t* padded, size_t padded_cap);
+/* the same with the caller's own suffix bits, appended verbatim as sha3_b does (sha3.c:414-429: two bits sfx[0], sfx[1],
+ * or four bits sfx[0..3]; e.g. "11" = RawSHAKE): nsfx in 0..8, bit i of the suffix = sfx_bits[i] & 1 */
+int mlkem_sha3_pad_suffix(const uint8_t* msg_bits, size_t nbits, const uint8_t* sfx_bits, unsigned nsfx, unsigned rate,
+                          uint8_t* padded, size_t padded_cap);
+
+/* ---- on-device exhaustive self-test of the exact fp32-pipe arithmetic ---------------------------------------------
+ * The kernels evaluate `% q` (ml_kem.c:83-97, :253-275, :287-442) with fp32 FMAs on integers below 2^24.  Sweep `which`
+ * (0 .. mlkem_selftest_count() - 1) checks one helper over its WHOLE input domain on the context's device against integer
+ * arithmetic (fred: |x| <= 2^24; twiddle products: 258 multipliers x |b| <= 10082; Compress_d: d = 1..11 x |x| <= 4095;
+ * CBD eta = 2 / 3: all 2^16 / 2^24 lane inputs; the base-case multiply-accumulate at the corners of its bound;
+ * canonicalisation).  Synchronises; *violations == 0 means the property holds on this device and build. */
+int mlkem_selftest_count(void);
+int mlkem_selftest(mlkem_ctx* ctx, int which, unsigned long long* violations);
 
 /* ---- batched KEM, host pointers (stage + run + synchronise) ----------------------------------------
  * These are the streaming front-end below with its default chunking: staging buffers, stream and context are cached
@@ -163,20 +181,66 @@ int mlkem_intt(size_t n, const uint16_t* f_hat, uint16_t* f);
 int mlkem_sample_ntt(size_t n, const uint8_t* seeds34, uint16_t* a_hat);
 int mlkem_sample_cbd(int eta, size_t n, const uint8_t* bytes, uint16_t* f);
 int mlkem_keccak_sponge(unsigned rate, size_t n, const uint8_t* padded, unsigned nblocks, uint8_t* out, unsigned outlen);
+/* Compress / Decompress (ml_kem.c:83-119) over n host values, any d in 1..12 (reference test Test_Archive/CompressDecompress_test04.c) */
+int mlkem_compress(int d, size_t n, const uint16_t* x, uint16_t* y);
+int mlkem_decompress(int d, size_t n, const uint16_t* y, uint16_t* x);
+/* All state the host-pointer calls cache is kept PER DEVICE (the HIP device current in the calling thread): threads that
+ * work on different devices share nothing.  mlkem_host_release() zeroes and frees all of it (contexts, streams, pinned and
+ * device staging) on every device; mlkem_stream_release() only the streaming engines. */
+void mlkem_host_release(void);
 
 /* ---- layout converters and streaming front-end --------------------------------------------------
  * The reference stores every byte in a 4-byte `union byte` cell (ml_kem.h:35-38; value in bits 0-7, upper bits
  * undefined).  Device-side converters at memory bandwidth: */
 int mlkem_cells_to_bytes_dev(mlkem_ctx* ctx, size_t n_cells, const uint32_t* cells, uint8_t* bytes, void* stream);
 int mlkem_bytes_to_cells_dev(mlkem_ctx* ctx, size_t n_cells, const uint8_t* bytes, uint32_t* cells, void* stream);
-/* Host-resident batches of any size: double-buffered pinned staging, H2D / kernels / D2H of chunk i overlap the host
- * copies of chunk i+1 (chunk_items = 0 -> 2^14).  Same results as the plain host-pointer calls; PCIe-bound. */
+/* Host-resident batches of any size in chunks (chunk_items = 0 -> 2^14, env MLKEM_STREAM_CHUNK_ITEMS): three streams
+ * (H2D / kernels / D2H) and three buffer sets ordered by events, so that H2D(i+1), kernels(i) and D2H(i-1) overlap (PCIe is
+ * full duplex).  Caller buffers that are pinned (hipHostMalloc, hipHostRegister or mlkem_host_register below) are handed to
+ * the DMA engines directly; pageable buffers go through pinned staging with threaded copies.  Same results as the
+ * plain host-pointer calls; PCIe-bound. */
 int mlkem_keygen_stream(int param_set, size_t n, const uint8_t* d, const uint8_t* z, uint8_t* ek, uint8_t* dk, size_t chunk_items);
 int mlkem_encaps_stream(int param_set, size_t n, const uint8_t* ek, const uint8_t* m, uint8_t* c, uint8_t* K, size_t chunk_items);
 int mlkem_decaps_stream(int param_set, size_t n, const uint8_t* dk, const uint8_t* c, uint8_t* K, int32_t* status, size_t chunk_items);
-/* The streaming calls keep two slots (stream, context, pinned + device staging buffers) cached between calls;
- * this zeroes and frees them. */
+/* The streaming calls keep their engine (streams, events, a context, pinned + device staging buffers) cached per device
+ * between calls; this zeroes and frees the engines of all devices. */
 void mlkem_stream_release(void);
+/* pin / unpin caller memory (hipHostRegister, portable across devices) so that the streaming and *_multi calls skip the
+ * staging copy for it */
+int mlkem_host_register(void* p, size_t bytes);
+int mlkem_host_unregister(void* p);
+
+/* ---- in-process sharding over several devices (BASELINE configs[4]: 2^23 items over 8 x MI355X) ------------
+ * The batch dimension is embarrassingly parallel: an mlkem_multi is a list of MEMBERS, each bound to one HIP device
+ * (`devices[r]`; NULL = devices 0 .. n_members-1; n_members = 0 and NULL = every visible device once).  A device may be
+ * listed more than once, which is how the sharded path is rehearsed on one GPU.  Member r of R takes the contiguous item
+ * range mlkem_shard_range(n, r, R) (item i -> member floor(i / (n/R)), remainder spread over the first members); there is
+ * no exchange between members, no collective and no RCCL.  The reference has no counterpart (single-threaded C). */
+typedef struct mlkem_multi mlkem_multi;
+int mlkem_multi_create(mlkem_multi** out, int n_members, const int* devices, size_t chunk_items);
+void mlkem_multi_destroy(mlkem_multi* mm);
+int mlkem_multi_members(const mlkem_multi* mm);
+int mlkem_multi_device(const mlkem_multi* mm, int member);
+int mlkem_shard_range(size_t n, int member, int n_members, size_t* start, size_t* stop);
+/* host-resident batch (same arguments as the *_stream calls): one host thread per member drives that member's own
+ * streaming engine on its device over its item range; returns when all members are done */
+int mlkem_keygen_multi(mlkem_multi* mm, int param_set, size_t n, const uint8_t* d, const uint8_t* z, uint8_t* ek, uint8_t* dk,
+                       size_t chunk_items);
+int mlkem_encaps_multi(mlkem_multi* mm, int param_set, size_t n, const uint8_t* ek, const uint8_t* m, uint8_t* c, uint8_t* K,
+                       size_t chunk_items);
+int mlkem_decaps_multi(mlkem_multi* mm, int param_set, size_t n, const uint8_t* dk, const uint8_t* c, uint8_t* K, int32_t* status,
+                       size_t chunk_items);
+/* device-resident shards: arrays of length mlkem_multi_members(); shard r (n_shard[r] items, layout as in the *_dev calls)
+ * lives on member r's device.  The work is enqueued on the member's own stream and the call returns without
+ * synchronising; the member streams are not ordered after any other stream, so the inputs must be complete when the
+ * call is made.  mlkem_multi_sync waits for every member. */
+int mlkem_keygen_multi_dev(mlkem_multi* mm, int param_set, const size_t* n_shard, const uint8_t* const* d, const uint8_t* const* z,
+                           uint8_t* const* ek, uint8_t* const* dk);
+int mlkem_encaps_multi_dev(mlkem_multi* mm, int param_set, const size_t* n_shard, const uint8_t* const* ek, const uint8_t* const* m,
+                           uint8_t* const* c, uint8_t* const* K);
+int mlkem_decaps_multi_dev(mlkem_multi* mm, int param_set, const size_t* n_shard, const uint8_t* const* dk, const uint8_t* const* c,
+                           uint8_t* const* K, int32_t* const* status);
+int mlkem_multi_sync(mlkem_multi* mm);
 
 /* ---- randomised wrappers: seeds drawn on the host with getrandom(2) ---------------- */
 /* replaces KEM_KeyGen(params)  ml_kem.c:1233-1252 for n key pairs */

@@ -17,6 +17,7 @@ Fixture families:
   G6 end-to-end   per parameter set: recipe seeds d=i, z=32+i, m=64+i in full, plus SEEDED_TRIPLES
                   triples from the documented SHAKE128 seed expander (digests + K in full)
   G7 negative     bad-ek accepted (F3), ml_errno codes of the public API
+  G9 suffix       sha3_b with other suffix cells than ml_kem.c passes (RawSHAKE "11", "10", "00", four bits "1011")
   G8 SHA-3        the 16 NIST FIPS-202 examples held by the reference's Test_Examples/SHA
                   (message bits + expected output, parsed from the data files), cross-checked
                   against the reference's sha3_b
@@ -245,6 +246,24 @@ def main():
                      "out": out[: len(got_hex)]})
     J["G8_nist_sha3"] = nist
     print(f"  {len(nist)} NIST SHA-3 examples reproduced by the reference sha3_b")
+
+    # ---- G4 over the whole 12-bit field, every d (Test_Archive/CompressDecompress_test04.c sweeps d = 1..12) ---------
+    npz["g4_compress_full"] = np.array([[ref.compress(x, d) for x in range(4096)] for d in range(1, 13)], np.uint16)
+    npz["g4_decompress_full"] = np.array([[ref.decompress(y, d) for y in range(4096)] for d in range(1, 13)], np.uint16)
+
+    # ---- G9: sha3_b appends the caller's suffix cells verbatim (sha3.c:414-429) -----------------------------------
+    # two-bit suffixes other than the hash "01" (RawSHAKE "11", and "10" / "00" to pin "verbatim"), NIST's message
+    # lengths; the lengths avoid the reference's latent pad bug (n + suffix + 2 = 0 mod r)
+    rng9 = np.random.default_rng(GOLDEN_SEED + 9)
+    raw = []
+    for cap in (256, 512):
+        for sfx in ((1, 1, 0, 0), (1, 0, 0, 0), (0, 0, 0, 0), (1, 0, 1, 1)):
+            for nbits in (0, 5, 30, 1600, 1605, 1630):
+                bits = rng9.integers(0, 2, nbits).astype(np.uint8)
+                got = ref.sha3_bits_sfx(bits, 512, cap, np.array(sfx, np.uint8))
+                raw.append({"cap": cap, "rate_bytes": (1600 - cap) // 8, "sfx": list(sfx), "msg_bits": "".join(map(str, bits)),
+                            "out": bytes(np.packbits(got, bitorder="little")).hex()})
+    J["G9_sha3_suffix"] = raw
 
     with open(os.path.join(OUT, "mlkem_golden.json"), "w") as f:
         json.dump(J, f, indent=1)

@@ -233,6 +233,13 @@ class Oracle:
         self.lib.orc_sponge_bits(rate, int(xof), _p8(bits), bits.size, _p8(out), outlen)
         return out
 
+    def sponge_bits_sfx(self, rate, sfx_bits, bits, outlen):
+        """bit-granular sponge with the caller's suffix bits appended verbatim (sha3.c:414-429)"""
+        bits, sfx = _u8(bits), _u8(sfx_bits)
+        out = np.zeros(outlen, np.uint8)
+        self.lib.orc_sponge_bits_sfx(rate, _p8(sfx), sfx.size, _p8(bits), bits.size, _p8(out), outlen)
+        return out
+
     def prf(self, s, b, eta):
         s = _u8(s, 32)
         out = np.zeros(64 * eta, np.uint8)
@@ -441,6 +448,13 @@ class Ref:
         bits = _u8(bits)
         out = np.zeros(d_bits, np.uint8)
         self.lib.ref_sha3_bits(_p8(bits), bits.size, d_bits, c_bits, int(xof), _p8(out))
+        return out
+
+    def sha3_bits_sfx(self, bits, d_bits, c_bits, sfx4):
+        """sha3_b with the caller's four suffix cells (sfx4[2] == 1: four suffix bits, else sfx4[0], sfx4[1])"""
+        bits, sfx = _u8(bits), _u8(sfx4, 4)
+        out = np.zeros(d_bits, np.uint8)
+        self.lib.ref_sha3_bits_sfx(_p8(bits), bits.size, d_bits, c_bits, _p8(sfx), _p8(out))
         return out
 
     def time_encaps_decaps(self, pset, ek, dk, m):

@@ -91,16 +91,17 @@ void orc_keccak_f1600(uint64_t A[25]) {
  * ---------------------------------------------------------------------------------------- */
 static void xor_bit(uint64_t st[25], size_t bitpos) { st[bitpos / 64] ^= (uint64_t)1 << (bitpos % 64); }
 
-void orc_sponge_bits(unsigned rate, int xof, const uint8_t *msg_bits, size_t nbits, uint8_t *out, size_t outlen) {
+void orc_sponge_bits_sfx(unsigned rate, const uint8_t *sfx_bits, unsigned nsfx, const uint8_t *msg_bits, size_t nbits,
+                         uint8_t *out, size_t outlen) {
     uint64_t st[25];
     const size_t rbits = (size_t)rate * 8;
     size_t pos = 0; /* bit position inside the current rate block */
     memset(st, 0, sizeof st);
-    /* message bits then suffix bits (sha3.c:423-429), then pad10*1 (sha3.c:226-240) */
-    uint8_t tail[6];
+    /* message bits, then the caller's suffix bits verbatim (sha3.c:414-429: two or four of them),
+     * then pad10*1 (sha3.c:226-240) */
+    uint8_t tail[9];
     size_t ntail = 0;
-    if (xof) { tail[0] = tail[1] = tail[2] = tail[3] = 1; ntail = 4; }
-    else { tail[0] = 0; tail[1] = 1; ntail = 2; }
+    for (unsigned i = 0; i < nsfx && i < 8; i++) tail[ntail++] = sfx_bits[i] & 1u;
     tail[ntail++] = 1; /* first pad bit */
     for (size_t i = 0; i < nbits + ntail; i++) {
         unsigned bit = i < nbits ? (msg_bits[i] & 1u) : tail[i - nbits];
@@ -119,6 +120,10 @@ void orc_sponge_bits(unsigned rate, int xof, const uint8_t *msg_bits, size_t nbi
         done += take;
         if (done < outlen) orc_keccak_f1600(st);
     }
+}
+void orc_sponge_bits(unsigned rate, int xof, const uint8_t *msg_bits, size_t nbits, uint8_t *out, size_t outlen) {
+    static const uint8_t hash_sfx[2] = {0, 1}, xof_sfx[4] = {1, 1, 1, 1}; /* sha3.c:408-436 as ml_kem.c calls it */
+    orc_sponge_bits_sfx(rate, xof ? xof_sfx : hash_sfx, xof ? 4 : 2, msg_bits, nbits, out, outlen);
 }
 
 void orc_sponge(unsigned rate, uint8_t suffix, const uint8_t *in, size_t inlen, uint8_t *out, size_t outlen) {
@@ -177,7 +182,10 @@ unsigned orc_bitrev7(unsigned r) { /* ml_kem.c:26-38 */
     return o;
 }
 
+/* Both take any 12-bit input like the reference's `union integer.t` field (ml_kem.c:20-23): the dividend fits the
+ * 24-bit `.l` field, the rounded quotient wraps at 12 bits. */
 unsigned orc_compress(unsigned x, unsigned d) { /* ml_kem.c:83-97 */
+    x &= 0xFFFu;
     if (d >= 12) return x;
     unsigned num = x << d;
     unsigned quo = num / ORC_Q, rem = num % ORC_Q;
@@ -186,11 +194,12 @@ unsigned orc_compress(unsigned x, unsigned d) { /* ml_kem.c:83-97 */
 }
 
 unsigned orc_decompress(unsigned y, unsigned d) { /* ml_kem.c:104-119 */
+    y &= 0xFFFu;
     if (d >= 12) return y;
     unsigned num = ORC_Q * y;
     unsigned quo = num >> d, rem = num & ((1u << d) - 1);
     if (rem >= (1u << (d - 1))) quo += 1;
-    return quo;
+    return quo & 0xFFFu;
 }
 
 void orc_byte_encode(const uint16_t F[256], unsigned d, uint8_t *B) { /* ml_kem.c:125-145 */

@@ -45,6 +45,8 @@ void orc_keccak_f1600(uint64_t st[25]);
 void orc_sponge(unsigned rate, uint8_t suffix, const uint8_t *in, size_t inlen, uint8_t *out, size_t outlen);
 /* Bit-granular sponge: msg as one bit per byte, nbits arbitrary (NIST 5-/30-/1605-/1630-bit examples). */
 void orc_sponge_bits(unsigned rate, int xof, const uint8_t *msg_bits, size_t nbits, uint8_t *out, size_t outlen);
+void orc_sponge_bits_sfx(unsigned rate, const uint8_t *sfx_bits, unsigned nsfx, const uint8_t *msg_bits, size_t nbits,
+                         uint8_t *out, size_t outlen);
 void orc_sha3_256(const uint8_t *in, size_t n, uint8_t out[32]);
 void orc_sha3_512(const uint8_t *in, size_t n, uint8_t out[64]);
 void orc_shake128(const uint8_t *in, size_t n, uint8_t *out, size_t outlen);

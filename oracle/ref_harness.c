@@ -258,6 +258,19 @@ void ref_sha3_bits(const uint8_t *msg_bits, unsigned n, unsigned d, unsigned c, 
     free(in); free(r);
 }
 
+/* The same with the caller's suffix cells handed to sha3_b verbatim (sha3.c:414-429): sfx[2] == 1 selects four suffix
+ * bits, otherwise sfx[0], sfx[1] are appended ("11" = RawSHAKE). */
+void ref_sha3_bits_sfx(const uint8_t *msg_bits, unsigned n, unsigned d, unsigned c, const uint8_t sfx4[4],
+                       uint8_t *out_bits) {
+    union bit *in = malloc(sizeof(union bit) * (n ? n : 1));
+    for (unsigned i = 0; i < n; i++) in[i].b = msg_bits[i] & 1;
+    union bit sfx[4];
+    for (int i = 0; i < 4; i++) sfx[i].b = sfx4[i] & 1;
+    union bit *r = sha3_b(in, n, d, c, sfx);
+    for (unsigned i = 0; i < d; i++) out_bits[i] = (uint8_t)r[i].b;
+    free(in); free(r);
+}
+
 /* ---- timing helper for bench.py's cpu_baseline ("reference" kind) -------------------- */
 #include <time.h>
 /* Runs Encaps_internal + KEM_Decaps on `pairs` key/message sets; returns elapsed seconds and

@@ -108,6 +108,9 @@ int emu_prf(int eta, size_t n, const uint8_t* in33, uint8_t* out) { return prf_l
 int emu_hash(int kind, size_t n, const uint8_t* msg, unsigned len, size_t stride, uint8_t* out) {
     return hash_launch(nullptr, kind, n, msg, len, stride, out);
 }
+int emu_compress_values(int decompress, int d, size_t n, const uint16_t* in, uint16_t* out) {
+    return compress_values_launch(nullptr, decompress != 0, d, n, in, out);
+}
 void emu_cells(int to_bytes, size_t n, const void* in, void* out) { cells_launch(nullptr, to_bytes != 0, n, in, out); }
 int emu_sponge_raw(unsigned rate, size_t n, const uint8_t* msg, unsigned nblocks, uint8_t* out, unsigned outlen, size_t out_stride) {
     return sponge_raw_launch(nullptr, rate, n, msg, nblocks, out, outlen, out_stride);
@@ -145,6 +148,15 @@ long emu_fmulmod_exhaustive(void) {
                 if ((((long)t2 - ti) % KQ) != 0) bad++;
             }
         }
+    }
+    return bad;
+}
+// fcanon_floor (mlkem_fntt.hpp): canonical representative by floor of the biased quotient, every |x| <= 2^20
+long emu_fcanon_floor_exhaustive(void) {
+    long bad = 0;
+    for (long x = -(1l << 20); x <= (1l << 20); x++) {
+        const long want = ((x % KQ) + KQ) % KQ;
+        if (fcanon_floor((float)x) != (float)want) bad++;
     }
     return bad;
 }

@@ -123,3 +123,62 @@ def test_shard_range(pkg):
         assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
         assert max(b - a for a, b in spans) - min(b - a for a, b in spans) <= 1
     assert pkg.shard_range(1 << 23, 3, 8) == (3 << 20, 4 << 20)   # config 5: item i -> GPU i >> 20
+
+
+def test_caller_supplied_outputs_are_validated(pkg):
+    """outputs reach the C-ABI as raw pointers, so a wrong device / dtype / shape / stride must be rejected on
+    the host (here on CPU tensors through a bare instance: no engine can be created without a GPU)."""
+    import torch
+    e = pkg.MLKEM.__new__(pkg.MLKEM)
+    e.torch, e.device = torch, torch.device("cpu")
+    good = torch.empty((4, 32), dtype=torch.uint8)
+    assert e._out(4, 32, given=good) is good
+    assert e._out(4, None, torch.int32, given=torch.empty(4, dtype=torch.int32)).shape == (4,)
+    bad = [torch.empty((3, 32), dtype=torch.uint8),                    # too few rows
+           torch.empty((4, 31), dtype=torch.uint8),                    # short rows
+           torch.empty((4, 32), dtype=torch.int64),                    # wrong element type
+           torch.empty((4, 64), dtype=torch.uint8)[:, ::2],            # non-contiguous
+           torch.empty((4, 32), dtype=torch.uint8, device="meta"),     # wrong device
+           [0] * 128]                                                  # not a tensor
+    for t in bad:
+        with pytest.raises(pkg.MLKEMError) as ex:
+            e._out(4, 32, given=t)
+        assert ex.value.code == -101
+    with pytest.raises(pkg.MLKEMError):
+        e._out(4, None, torch.int32, given=torch.empty(4, dtype=torch.int64))   # status must be int32
+    e._ctx = None   # nothing to destroy
+
+
+def test_multi_and_host_state_entry_points_fail_loudly_without_gpu(pkg):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    lib = pkg.load_library()
+    h = C.c_void_p()
+    assert lib.mlkem_multi_create(C.byref(h), 2, (C.c_int * 2)(0, 0), 0) == -100 and not h.value
+    with pytest.raises(pkg.MLKEMError):
+        pkg.MLKEMMulti(768, devices=[0, 0])
+    lib.mlkem_host_release()     # nothing cached: a no-op, must not crash
+    lib.mlkem_stream_release()
+    a, b = C.c_size_t(), C.c_size_t()
+    assert lib.mlkem_shard_range(1 << 23, 3, 8, C.byref(a), C.byref(b)) == 0 and (a.value, b.value) == (3 << 20, 4 << 20)
+    assert lib.mlkem_shard_range(10, 3, 3, C.byref(a), C.byref(b)) == -101
+    for n, w in ((1000, 3), (5, 8), (0, 2)):
+        for r in range(w):
+            lib.mlkem_shard_range(n, r, w, C.byref(a), C.byref(b))
+            assert (a.value, b.value) == pkg.shard_range(n, r, w)
+
+
+def test_sha3_pad_suffix_host_helper(pkg):
+    """mlkem_sha3_pad_suffix appends the caller's suffix bits verbatim, then pad10*1 (pure host code)."""
+    import numpy as np
+    lib = pkg.load_library()
+    bits = np.array([1, 0, 1], np.uint8)
+    out = np.zeros(168, np.uint8)
+    sfx = np.array([1, 1], np.uint8)   # RawSHAKE
+    assert lib.mlkem_sha3_pad_suffix(bits.ctypes.data, 3, sfx.ctypes.data, 2, 168, out.ctypes.data, out.size) == 1
+    assert out[0] == 0b00111101 and out[167] == 0x80 and not out[1:167].any()    # 101 | 11 | 1, LSB first
+    out2 = np.zeros(168, np.uint8)
+    assert lib.mlkem_sha3_pad_bits(bits.ctypes.data, 3, 1, 168, out2.ctypes.data, out2.size) == 1
+    assert out2[0] == 0b11111101 and out2[167] == 0x80
+    assert lib.mlkem_sha3_pad_suffix(bits.ctypes.data, 3, sfx.ctypes.data, 9, 168, out.ctypes.data, out.size) == -101

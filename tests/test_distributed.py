@@ -1,7 +1,9 @@
-"""CPU tier: the N>1 path (contiguous shards, no data-path collective) with world_size-2 gloo.
-Each rank takes shard_range(n, rank, world) of a globally indexed batch; because the GPU engine cannot run
-here, the per-shard compute is the oracle (checker stand-in) — what is under test is the sharding, the
-global-index seeding and bench.py's barrier / max-over-ranks plumbing."""
+"""The N > 1 path (contiguous shards, no data-path collective).
+
+CPU tier  world_size-2 gloo: shard_range, the global-index seeding and bench.py's barrier / max-over-ranks plumbing; the
+          per-shard compute is the oracle there (the HIP engine cannot run without a GPU), i.e. the checker stands in.
+GPU tier  the same two-rank job with every shard computed by the HIP ENGINE (both ranks on device 0, gloo for the barrier,
+          as bench.py's rehearsal mode does) against the single-context bytes and the oracle."""
 import hashlib
 import os
 import socket
@@ -23,28 +25,49 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, n, out_dir):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+def _shard_inputs(bench, lo, hi):
+    return tuple(np.frombuffer(b"".join(bench.expand(lbl, i) for i in range(lo, hi)), np.uint8).reshape(-1, 32).copy()
+                 for lbl in ("mlkem-bench-d", "mlkem-bench-z", "mlkem-bench-m"))
+
+
+def _digests(c, K):
+    return np.frombuffer(b"".join(hashlib.sha256(bytes(c[i]) + bytes(K[i])).digest() for i in range(len(K))), np.uint8)
+
+
+def _worker(rank, world, port, n, out_dir, use_engine):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      LOCAL_WORLD_SIZE=str(world))
     import bench
-    from oracle.loader import Oracle
     pkg = ge.load_package()
+    if use_engine:
+        # exactly bench.py's set-up: fewer GPUs than ranks -> ranks share device 0, gloo
+        r2, w2, local = bench.dist_setup(world, rehearse=True)
+        assert (r2, w2, local) == (rank, world, 0) and bench.SHARED_GPU
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     lo, hi = pkg.shard_range(n, rank, world)
-    d = np.frombuffer(b"".join(bench.expand("mlkem-bench-d", i) for i in range(lo, hi)), np.uint8).reshape(-1, 32)
-    z = np.frombuffer(b"".join(bench.expand("mlkem-bench-z", i) for i in range(lo, hi)), np.uint8).reshape(-1, 32)
-    m = np.frombuffer(b"".join(bench.expand("mlkem-bench-m", i) for i in range(lo, hi)), np.uint8).reshape(-1, 32)
-    orc = Oracle()
-    ek, dk = orc.keygen(512, d, z)
-    c, K = orc.encaps(512, ek, m)
-    K2, st = orc.decaps(512, dk, c)
+    d, z, m = _shard_inputs(bench, lo, hi)
+    if use_engine:
+        eng = pkg.MLKEM(512, device=0, chunk_items=64)     # the HIP engine; fails loudly if the extension is missing
+        ek, dk = eng.keygen(torch.from_numpy(d), torch.from_numpy(z))
+        c, K = eng.encaps(ek, torch.from_numpy(m))
+        K2, st = eng.decaps(dk, c)
+        torch.cuda.synchronize()
+        c, K, K2, st = (t.cpu().numpy() for t in (c, K, K2, st))
+        eng.close()
+    else:
+        from oracle.loader import Oracle
+        orc = Oracle()
+        ek, dk = orc.keygen(512, d, z)
+        c, K = orc.encaps(512, ek, m)
+        K2, st = orc.decaps(512, dk, c)
     assert (K2 == K).all() and (st == 0).all()
     bench.barrier(world)
-    t = bench.max_over_ranks(float(rank + 1), world, torch.device("cpu"))
+    t = bench.max_over_ranks(float(rank + 1), world, torch.device("cuda", 0) if use_engine else torch.device("cpu"))
     assert t == float(world)
     # gather per-item digests on rank 0 (test-only collective; the product's data path has none)
-    dig = np.frombuffer(b"".join(hashlib.sha256(bytes(c[i]) + bytes(K[i])).digest() for i in range(hi - lo)), np.uint8)
     gathered = [None] * world
-    dist.all_gather_object(gathered, (lo, hi, dig.tobytes()))
+    dist.all_gather_object(gathered, (lo, hi, _digests(c, K).tobytes()))
     if rank == 0:
         np.save(os.path.join(out_dir, "digests.npy"), np.frombuffer(b"".join(g[2] for g in sorted(gathered)), np.uint8))
         spans = sorted((g[0], g[1]) for g in gathered)
@@ -52,18 +75,37 @@ def _worker(rank, world, port, n, out_dir):
     dist.destroy_process_group()
 
 
-def test_two_rank_shards_equal_single_process(tmp_path, oracle):
+def _oracle_digests(oracle, n):
     import bench
-    n, world = 9, 2
-    mp.spawn(_worker, args=(world, _free_port(), n, str(tmp_path)), nprocs=world, join=True)
-    got = np.load(tmp_path / "digests.npy")
-    d = np.frombuffer(b"".join(bench.expand("mlkem-bench-d", i) for i in range(n)), np.uint8)
-    z = np.frombuffer(b"".join(bench.expand("mlkem-bench-z", i) for i in range(n)), np.uint8)
-    m = np.frombuffer(b"".join(bench.expand("mlkem-bench-m", i) for i in range(n)), np.uint8)
+    d, z, m = _shard_inputs(bench, 0, n)
     ek, dk = oracle.keygen(512, d, z)
     c, K = oracle.encaps(512, ek, m)
-    want = np.frombuffer(b"".join(hashlib.sha256(bytes(c[i]) + bytes(K[i])).digest() for i in range(n)), np.uint8)
-    assert (got == want).all()
+    return _digests(c, K)
+
+
+def test_two_rank_shards_equal_single_process(tmp_path, oracle):
+    n, world = 9, 2
+    mp.spawn(_worker, args=(world, _free_port(), n, str(tmp_path), False), nprocs=world, join=True)
+    assert (np.load(tmp_path / "digests.npy") == _oracle_digests(oracle, n)).all()
+
+
+@pytest.mark.gpu
+def test_two_rank_shards_computed_by_the_hip_engine(tmp_path, oracle):
+    """Two freshly spawned ranks, each with its own engine context on device 0, each computing shard_range(n, rank, 2) of
+    the globally indexed batch: concatenated, the shards equal the oracle's bytes for the whole batch and the
+    single-context engine's."""
+    n, world = 777, 2     # ragged: 389 + 388, several 64-item chunks per rank
+    mp.spawn(_worker, args=(world, _free_port(), n, str(tmp_path), True), nprocs=world, join=True)   # before this process touches the GPU
+    got = np.load(tmp_path / "digests.npy")
+    assert (got == _oracle_digests(oracle, n)).all()
+    import bench
+    pkg = ge.load_package()
+    d, z, m = _shard_inputs(bench, 0, n)
+    eng = pkg.MLKEM(512, device=0)
+    ek, dk = eng.keygen(torch.from_numpy(d), torch.from_numpy(z))
+    c, K = eng.encaps(ek, torch.from_numpy(m))
+    assert (got == _digests(c.cpu().numpy(), K.cpu().numpy())).all()
+    eng.close()
 
 
 def test_bench_requires_torchrun_for_multi_gpu(monkeypatch):

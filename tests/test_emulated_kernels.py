@@ -314,3 +314,22 @@ def test_emu_cell_converters(emu):
         back = np.full(n + 1, 0xFFFFFFFF, np.uint32)
         emu.emu_cells(0, C.c_size_t(n), b.ctypes.data_as(C.c_void_p), back.ctypes.data_as(C.c_void_p))
         assert (back[:n] == b).all() and back[n] == 0xFFFFFFFF
+
+
+def test_emu_compress_values_every_d_whole_field(emu, golden_npz):
+    """k_compress_values (general Compress / Decompress entry, any d in 1..12, any 12-bit input) against the tables the
+    real reference produced (golden G4, whole 12-bit field); junk above bit 11 is ignored like the reference's bit-field."""
+    x = (np.arange(4096, dtype=np.uint16) | np.uint16(0xF000 & (np.arange(4096) * 4096))).astype(np.uint16)
+    x = np.concatenate([x, x[:5]])   # a ragged tail past the 8-value groups
+    for d in range(1, 13):
+        out = np.zeros_like(x)
+        assert emu.emu_compress_values(0, d, C.c_size_t(x.size), p16(x), p16(out)) == 0
+        assert (out[:4096] == golden_npz["g4_compress_full"][d - 1]).all() and (out[4096:] == out[:5]).all(), d
+        assert emu.emu_compress_values(1, d, C.c_size_t(x.size), p16(x), p16(out)) == 0
+        assert (out[:4096] == golden_npz["g4_decompress_full"][d - 1]).all(), d
+    assert emu.emu_compress_values(0, 13, C.c_size_t(8), p16(x), p16(out)) != 0
+
+
+def test_emu_fcanon_floor_exhaustive(emu):
+    emu.emu_fcanon_floor_exhaustive.restype = C.c_long
+    assert emu.emu_fcanon_floor_exhaustive() == 0

@@ -192,3 +192,20 @@ def test_g7_init_errno(oracle, golden):
         class P(C.Structure):
             _fields_ = [("f", C.c_uint * 9)]
         assert oracle.lib.orc_params_init(int(s), C.byref(P())) == rc
+
+
+def test_g4_full_field_tables_and_g9_suffix_vectors(oracle, golden, golden_npz):
+    """The fixtures added in round 2 (generated from the real reference by oracle/gen_golden.py): Compress / Decompress
+    over the whole 12-bit field for d = 1..12, and sha3_b with caller-chosen suffix bits."""
+    comp, dec = golden_npz["g4_compress_full"], golden_npz["g4_decompress_full"]
+    for d in range(1, 13):
+        assert [oracle.compress(v, d) for v in range(4096)] == comp[d - 1].tolist()
+        assert [oracle.decompress(v, d) for v in range(4096)] == dec[d - 1].tolist()
+        if d < 12:   # the older tables are the sub-ranges
+            assert (comp[d - 1, :3329] == golden_npz["g4_compress"][d - 1]).all()
+            assert (dec[d - 1, : 1 << d] == golden_npz["g4_decompress"][d - 1, : 1 << d]).all()
+    for g in golden["G9_sha3_suffix"]:
+        bits = np.array([int(ch) for ch in g["msg_bits"]], np.uint8)
+        sfx = g["sfx"][: 4 if g["sfx"][2] == 1 else 2]
+        want = np.frombuffer(bytes.fromhex(g["out"]), np.uint8)
+        assert (oracle.sponge_bits_sfx(g["rate_bytes"], sfx, bits, want.size) == want).all()

@@ -68,3 +68,25 @@ def test_reference_sha3_bit_api_matches_oracle_bits(ref, oracle):
                 continue  # the reference's latent pad bug; the oracle follows FIPS 202 there
             want = np.packbits(ref.sha3_bits(bits, dbits, cap, xof), bitorder="little")
             assert (oracle.sponge_bits(rate, xof, bits, dbits // 8) == want).all(), (nbits, rate)
+
+
+def test_compress_decompress_whole_12bit_field_every_d(ref, oracle, golden_npz):
+    """Test_Archive/CompressDecompress_test04.c sweeps d = 1..12; here every 12-bit input (values >= q and >= 2^d
+    included: the reference's field arithmetic wraps at 12 bits): oracle == live reference == committed tables."""
+    for d in range(1, 13):
+        for v in range(4096):
+            assert oracle.compress(v, d) == ref.compress(v, d) == golden_npz["g4_compress_full"][d - 1, v], (d, v)
+            assert oracle.decompress(v, d) == ref.decompress(v, d) == golden_npz["g4_decompress_full"][d - 1, v], (d, v)
+        assert all(oracle.compress(oracle.decompress(y, d), d) == y for y in range(1 << min(d, 11)))   # test04's property
+
+
+def test_sha3_b_appends_the_callers_suffix_verbatim(ref, oracle, golden):
+    """sha3.c:414-429: sfx[2] picks the suffix LENGTH, the bits themselves are the caller's (RawSHAKE "11", ...)."""
+    for g in golden["G9_sha3_suffix"]:
+        bits = np.array([int(ch) for ch in g["msg_bits"]], np.uint8)
+        sfx = np.array(g["sfx"], np.uint8)
+        nsfx = 4 if sfx[2] == 1 else 2
+        want = np.frombuffer(bytes.fromhex(g["out"]), np.uint8)
+        got_ref = np.packbits(ref.sha3_bits_sfx(bits, 8 * want.size, g["cap"], sfx), bitorder="little")
+        assert (got_ref == want).all()
+        assert (oracle.sponge_bits_sfx(g["rate_bytes"], sfx[:nsfx], bits, want.size) == want).all(), g["sfx"]

@@ -11,7 +11,13 @@ import argparse
 import collections
 import csv
 import json
+import os
 import re
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--fetch", required=True)
@@ -61,7 +67,17 @@ for k in sorted(fetch):
                                        "read_raw_per_dispatch": rd, "read_x2_per_dispatch": 2 * rd, "write_per_dispatch": wr}
     raw += launches[label] * (rd + wr)
     corr += launches[label] * (2 * rd + wr)
+import bench as bench_mod  # noqa: E402  (source_id: the hash bench.py checks before it attaches this file)
+
+try:
+    git_head = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True).stdout.strip()
+    dirty = bool(subprocess.run(["git", "-C", ROOT, "status", "--porcelain", "--", "crystals-kyber_amd/csrc", "include"],
+                                capture_output=True, text=True).stdout.strip())
+except OSError:
+    git_head, dirty = "?", False
 out = {"workload": "%s batch %d chunk %s" % (a.workload, bench["config"]["batch_per_gpu"], bench["config"].get("chunk_items")),
+       "batch": bench["config"]["batch_per_gpu"], "source_id": bench_mod.source_id(),
+       "git_head": git_head + ("+uncommitted kernel changes" if dirty else ""),
        "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, with --kernel-trace), tools/pmc_traffic.py",
        "hbm_bytes_per_step_raw": raw, "hbm_bytes_per_step_corrected": corr,
        "note": "corrected = (2*FETCH_SIZE + WRITE_SIZE)*1024 as MI355X_MICROARCH.md prescribes for gfx950; raw FETCH under-reports "
