@@ -106,11 +106,30 @@ def max_over_ranks(x, world, device):
     return float(t.item())
 
 
+def host_cores():
+    """Host cores this process can really use: the affinity mask, capped by the cgroup CPU quota when there is one (a GPU
+    box hands a job a share of its CPUs through cpu.max while the affinity mask still shows every core)."""
+    n = max(1, len(os.sched_getaffinity(0)))
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                quota, period = txt[0], float(txt[1])
+            else:
+                quota, period = txt[0], float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota not in ("max", "-1") and float(quota) > 0:
+                n = min(n, max(1, int(float(quota) / period + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
 def cpu_baseline(pset, ek, dk, m, c_gpu, K_gpu, want_seconds=20.0):
     """Time the reference (or the port) on the host cores over a bounded sample of the SAME items."""
     from concurrent.futures import ThreadPoolExecutor
     from oracle import loader
-    cores = max(1, len(os.sched_getaffinity(0)))   # every host core this process may run on; the count is reported
+    cores = host_cores()   # every host core this process may use (affinity mask and cgroup quota); the count is reported
     n_all = m.shape[0]
     use_ref = loader.Ref.available()
     if use_ref:   # calibrate on one pair (30-80 ms per pair per core at -O2), then size for ~want_seconds of CPU work

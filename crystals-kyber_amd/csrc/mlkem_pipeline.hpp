@@ -14,6 +14,8 @@
 #include "mlkem_kernels.hpp"
 #include "mlkem_sampler.hpp"
 #include "mlkem_arith.hpp"
+#include "mlkem_rntt.hpp"
+#include <stdlib.h>
 #ifndef MLKEM_EMU
 #include <vector>
 #endif
@@ -435,9 +437,37 @@ inline size_t poly_grid(size_t n) {
     const size_t cap = 256 * 16;   // 256 CUs x a few workgroups, grid-stride for the rest
     return g < cap ? g : cap;
 }
+// two polynomials per wave and iteration, all in registers (mlkem_rntt.hpp); MLKEM_NTT_LDS=1 selects the one-polynomial-
+// per-wave LDS form the K-PKE kernels use (A/B measurements)
+inline bool ntt_use_lds() {
+#ifdef MLKEM_EMU
+    const bool v = getenv("MLKEM_NTT_LDS") && atoi(getenv("MLKEM_NTT_LDS")) == 1;   // the tests flip it between calls
+#else
+    static const bool v = getenv("MLKEM_NTT_LDS") && atoi(getenv("MLKEM_NTT_LDS")) == 1;
+#endif
+    return v;
+}
+// persistent grid of the register NTT (measured with tools/ntt_ubench.hip, profiles/r02_ntt_design.txt: 12288-16384
+// workgroups are best, 2^20 polynomials = 5.3 wave-iterations each; below 2048 the tail dominates; MLKEM_NTT_GRID overrides)
+inline size_t ntt_grid_cap() {
+    static const size_t v = [] {
+        const char* e = getenv("MLKEM_NTT_GRID");
+        const long long x = e ? atoll(e) : 0;
+        return x > 0 ? (size_t)x : (size_t)(256 * 48);
+    }();
+    return v;
+}
 inline void ntt_launch(stream_t st, bool inverse, size_t n, const uint16_t* in, uint16_t* out) {
-    if (inverse) launch("k_intt_batch", k_ntt_batch<true>, poly_grid(n), WAVE * ARITH_WAVES, st, n, in, out);
-    else launch("k_ntt_batch", k_ntt_batch<false>, poly_grid(n), WAVE * ARITH_WAVES, st, n, in, out);
+    if (ntt_use_lds()) {
+        if (inverse) launch("k_intt_batch", k_ntt_batch<true>, poly_grid(n), WAVE * ARITH_WAVES, st, n, in, out);
+        else launch("k_ntt_batch", k_ntt_batch<false>, poly_grid(n), WAVE * ARITH_WAVES, st, n, in, out);
+        return;
+    }
+    size_t grid = ceil_div(ceil_div(n, 4), RNTT_WAVES);
+    const size_t cap = ntt_grid_cap();
+    if (grid > cap) grid = cap;
+    if (inverse) launch("k_intt_batch", k_ntt4_batch<true>, grid, WAVE * RNTT_WAVES, st, n, in, out);
+    else launch("k_ntt_batch", k_ntt4_batch<false>, grid, WAVE * RNTT_WAVES, st, n, in, out);
 }
 inline void basemul_launch(stream_t st, size_t n, const uint16_t* a, const uint16_t* b, uint16_t* h) {
     launch("k_basemul_batch", k_basemul_batch, poly_grid(n), WAVE * ARITH_WAVES, st, n, a, b, h);

@@ -6,15 +6,17 @@
 // on gfx950 itself — the hardware FMA, v_cvt_f32_ubyteN, hipcc's constant folding and contraction choices — over the FULL
 // input domain of each helper.  Every sweep adds its violations to one 64-bit counter; zero means the property holds.
 //   sweep 0  fred(x)                                   every integer |x| <= 2^24
-//   sweep 1  fmulmod_shoup / fmulmod (both forms)      (+-128 zetas, +-128^-1) x every |b| <= 10082
+//   sweep 1  fmulmod_shoup / fmulmod (both forms)      (+-128 zetas, +-128^-1, +-zeta_1/128) x every |b| <= 10082
 //   sweep 2  compress_f<D>, D = 1..11                  every |x| <= 4095 (any representative)
 //   sweep 3  cbd_eval_f<2>                             all 2^16 lane inputs
 //   sweep 4  cbd_eval_f<3>                             all 2^24 lane inputs
 //   sweep 5  basemul_term (the body of basemul_acc_f)  every a in [0,4095] x every |y| <= 1665 with the other product
 //                                                      and the accumulator pinned at each corner of their ranges
 //   sweep 6  fcanon(x), fcanon_floor(x)                every |x| <= 2^20 (outputs canonical in [0, q))
+//   sweep 7  fmulmod_shoup by 1 (the reduction of the cross-lane butterflies, mlkem_rntt.hpp)   every |x| <= 2^22
 #pragma once
 #include "mlkem_arith.hpp"
+#include "mlkem_rntt.hpp"
 
 namespace mlkem {
 
@@ -45,10 +47,10 @@ __global__ void __launch_bounds__(256) k_selftest(int sweep, unsigned long long*
             if (!centred_ok(fred((float)x), x)) bad++;
         }
     } else if (sweep == 1) {
-        const long long per = 2 * 10082 + 1, total = 258 * per;
+        const long long per = 2 * 10082 + 1, total = 260 * per;
         for (long long i = (long long)tid; i < total; i += (long long)nthreads) {
             const int wi = (int)(i / per), b = (int)(i % per) - 10082;
-            Tw w = (wi >> 1) < 128 ? ZETA_F.z[wi >> 1] : F_INV128;
+            Tw w = (wi >> 1) < 128 ? ZETA_F.z[wi >> 1] : (wi >> 1) == 128 ? F_INV128 : F_INV128_Z1;
             if (wi & 1) w = tw_neg(w);
             const long long exact = (long long)(int)w.z * b;
             if (!centred_ok(fmulmod_shoup(w, (float)b), exact)) bad++;
@@ -106,11 +108,17 @@ __global__ void __launch_bounds__(256) k_selftest(int sweep, unsigned long long*
             if (c != (float)want) bad++;
         }
     }
+    else if (sweep == 7) {
+        for (long long i = (long long)tid; i <= (1ll << 23); i += (long long)nthreads) {
+            const long long x = i - (1ll << 22);
+            if (!centred_ok(fmulmod_shoup(TW_ONE, (float)x), x)) bad++;
+        }
+    }
     // one atomic per wave
     for (int off = 32; off > 0; off >>= 1) bad += __shfl_xor(bad, off);
     if ((threadIdx.x & 63) == 0 && bad) atomicAdd(bad_out, bad);
 }
 
-constexpr int SELFTEST_SWEEPS = 7;
+constexpr int SELFTEST_SWEEPS = 8;
 
 }   // namespace mlkem

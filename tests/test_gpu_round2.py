@@ -53,8 +53,8 @@ def test_fp32_arithmetic_exhaustive_on_device(pkg, eng):
     over |x| <= 4095; cbd_eval_f<2> / <3> over all 2^16 / 2^24 lane inputs; the base-case multiply-accumulate at the corners
     of its bound over every (a, y); canonicalisation over |x| <= 2^20 -- each against integer `% q` arithmetic computed on
     the device (ml_kem.c:83-97, :253-275, :287-442).  Zero violations."""
-    assert pkg.load_library().mlkem_selftest_count() == 7
-    assert eng.selftest() == [0] * 7
+    assert pkg.load_library().mlkem_selftest_count() == 8
+    assert eng.selftest() == [0] * 8
 
 
 def test_selftest_counter_actually_counts(pkg, eng):
@@ -64,6 +64,37 @@ def test_selftest_counter_actually_counts(pkg, eng):
     v = C.c_ulonglong(777)
     assert lib.mlkem_selftest(eng._ctx, 99, C.byref(v)) == -101 and v.value == 777
     assert lib.mlkem_selftest(eng._ctx, 3, C.byref(v)) == 0 and v.value == 0
+
+
+# ---- the register NTT (two polynomials per wave, permlane swaps + DPP butterflies) on the real lanes ---------------------
+def test_register_ntt_extremes_and_reference_behaviour_above_q(pkg, eng, torch, oracle):
+    """mlkem_rntt.hpp on gfx950: v_permlane32/16_swap and v_fmac_f32_dpp only exist on the device, so the layouts are
+    checked here against the oracle on inputs built to hit every lane / register position and the lazy bounds: unit
+    vectors at every coefficient index, all-maximum polynomials, alternating extremes, random canonical and random raw
+    12-bit polynomials (forward: the reference's non-modular arithmetic above q is reproduced exactly, e.g. NTT of
+    4095 x^0 has 4095 at index 254; inverse: inputs >= q are reduced first, the reference's result there is
+    compiler-dependent), odd and even batch sizes, and the LDS form of the same transform."""
+    rng = np.random.default_rng(77)
+    unit = np.zeros((256, 256), np.uint16)
+    unit[np.arange(256), np.arange(256)] = 3328
+    ext = np.zeros((8, 256), np.uint16)
+    ext[0] = 3328; ext[1] = 4095; ext[2, ::2] = 3328; ext[3, 1::2] = 4095
+    for b in range(4):
+        ext[4 + b] = np.where(np.arange(256) & (1 << (2 * b + 1)), 3328, 0)
+    one = np.zeros((1, 256), np.uint16)
+    one[0, 0] = 4095
+    cases = [unit, unit[:255], ext, one, rng.integers(0, 3329, (1001, 256)).astype(np.uint16),
+             rng.integers(0, 4096, (1000, 256)).astype(np.uint16)]
+    for a in cases:
+        da = dev(torch, a.view(np.int16))
+        want_f = oracle.ntt(a)
+        want_i = oracle.intt(a % 3329)
+        assert (host(eng.ntt(da)).view(np.uint16) == want_f).all(), a.shape
+        assert (host(eng.intt(da)).view(np.uint16) == want_i).all(), a.shape
+    assert oracle.ntt(one)[0, 254] == 4095
+    f = rng.integers(0, 3329, (513, 256)).astype(np.uint16)
+    fh = eng.ntt(dev(torch, f.view(np.int16)))
+    assert (host(eng.intt(fh)).view(np.uint16) == f).all()
 
 
 # ---- Compress / Decompress for every d (Test_Archive/CompressDecompress_test04.c) ------------------------------------
