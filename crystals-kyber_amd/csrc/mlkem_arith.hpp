@@ -37,7 +37,16 @@ __device__ __forceinline__ void store_poly_nat(uint16_t* p, const int (&x)[4]) {
     v.y = ((uint32_t)x[2] & 0xFFFFu) | ((uint32_t)x[3] << 16);
     *reinterpret_cast<uint2*>(p + 4 * lane_id()) = v;
 }
-__device__ __forceinline__ uint2 load_poly_raw(const uint16_t* p) { return *reinterpret_cast<const uint2*>(p + 4 * lane_id()); }
+#ifndef MLKEM_EXP_A384
+#define MLKEM_EXP_A384 0
+#endif
+__device__ __forceinline__ uint2 load_poly_raw(const uint16_t* p) {
+#if MLKEM_EXP_A384   // TIMING EXPERIMENT ONLY (wrong results): the wave touches 384 of the polynomial's 512 bytes
+    return *reinterpret_cast<const uint2*>(p + 3 * lane_id());
+#else
+    return *reinterpret_cast<const uint2*>(p + 4 * lane_id());
+#endif
+}
 __device__ __forceinline__ void poly_raw_to_f(const uint2 v, float (&x)[4]) {
     x[0] = (float)(v.x & 0xFFFFu); x[1] = (float)(v.x >> 16);
     x[2] = (float)(v.y & 0xFFFFu); x[3] = (float)(v.y >> 16);
@@ -390,38 +399,7 @@ k_keygen(size_t n, const uint16_t* __restrict__ A, const uint8_t* __restrict__ p
 // ================================================================================================
 // stand-alone primitives (C-ABI: mlkem_ntt / mlkem_intt / mlkem_multiply_ntts / mlkem_sample_cbd)
 // ================================================================================================
-// NTT / InverseNTT over n polynomials (ml_kem.c:287 / :336), uint16 in/out, canonical output.  One polynomial per
-// wave and iteration, grid-stride with the next polynomial requested before the current one is transformed;
-// inputs are taken mod 2^12 like the reference's 12-bit fields.
-template <bool INVERSE>
-__global__ void __launch_bounds__(WAVE * ARITH_WAVES) k_ntt_batch(size_t n, const uint16_t* __restrict__ in, uint16_t* __restrict__ out) {
-    __shared__ __attribute__((aligned(16))) float xch_all[ARITH_WAVES][256];
-    const int wv = (int)(threadIdx.x >> 6);
-    NttTwiddlesF tw;
-    load_twiddles_f(tw);
-    const size_t stride = (size_t)gridDim.x * ARITH_WAVES;
-    size_t p = (size_t)blockIdx.x * ARITH_WAVES + wv;
-    if (p >= n) return;
-    uint2 v_next = load_poly_raw(in + p * 256);
-    for (; p < n; p += stride) {
-        const uint2 v = v_next;
-        if (p + stride < n) v_next = load_poly_raw(in + (p + stride) * 256);
-        float x[4];
-        x[0] = (float)(v.x & 0xFFFu); x[1] = (float)((v.x >> 16) & 0xFFFu);
-        x[2] = (float)(v.y & 0xFFFu); x[3] = (float)((v.y >> 16) & 0xFFFu);
-        if constexpr (INVERSE) {
-#pragma unroll
-            for (int m = 0; m < 4; m++) x[m] = fred(x[m]);
-            wave_intt_f(x, xch_all[wv], tw);
-        } else {
-            wave_ntt_f(x, xch_all[wv], tw);
-        }
-        int o[4];
-#pragma unroll
-        for (int m = 0; m < 4; m++) o[m] = fcanon(x[m]);
-        store_poly_nat(out + p * 256, o);
-    }
-}
+// (the stand-alone NTT / InverseNTT kernels live in mlkem_rntt.hpp: four polynomials per wave in registers)
 
 // MultiplyNTTs (ml_kem.c:415-442): h = a o b, one polynomial pair per wave; inputs may be any 12-bit value
 __global__ void __launch_bounds__(WAVE * ARITH_WAVES) k_basemul_batch(size_t n, const uint16_t* __restrict__ a, const uint16_t* __restrict__ b,

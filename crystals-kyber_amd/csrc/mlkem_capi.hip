@@ -619,7 +619,7 @@ size_t default_stream_chunk() {
         long long v = atoll(e);
         if (v > 0) return (size_t)v;
     }
-    return (size_t)1 << 14;   // measured best on MI355X (tools/stream_bench.py)
+    return (size_t)1 << 15;   // measured best on MI355X for pageable and pinned buffers (tools/stream_bench.py, profiles/r02_stream_bench.json)
 }
 
 // runs on the calling thread; the engine's device must be current

@@ -135,6 +135,7 @@ struct ChunkPipe {
     stream_t main;
     bool overlap;
     int i = 0;
+    stream_t last_arith = nullptr;
     ChunkPipe(const Workspace& w, stream_t st, size_t nchunks) : ws(w), main(st), overlap(w.helper != nullptr && nchunks > 1) {}
     int begin_chunk() {                       // buffer for the next chunk; `main` waits until its previous user is done
         const int b = overlap ? (i & 1) : 0;
@@ -165,14 +166,25 @@ inline size_t min_sz(size_t a, size_t b) { return a < b ? a : b; }
 // the leftover list (ml_kem.c:189-245, :496-515)
 // n_xof_items / n_prf_items: items whose matrix / PRF rows are produced (equal except for shared-key batches, where the
 // matrix is sampled once and the PRF rows per item)
-inline void launch_sample_split(stream_t st, const ParamSet& p, size_t n_xof_items, size_t n_prf_items, const uint8_t* rho,
-                                size_t rho_stride, int transpose, const uint8_t* r, int prf_per_item, int n_eta1, const Workspace& ws);
+// `tail_st`: stream of the leftover pass.  It only has to finish before the arithmetic kernel that consumes the matrix, so
+// the chunk loops put it on the arithmetic stream: with MLKEM_OVERLAP=1 that is the helper stream and the (latency-bound,
+// one wave per CU) leftover pass runs beside the next chunk's three-block kernel instead of in front of it.
+inline void launch_sample_split(stream_t st, stream_t tail_st, const ParamSet& p, size_t n_xof_items, size_t n_prf_items, const uint8_t* rho,
+                                size_t rho_stride, int transpose, const uint8_t* r, int prf_per_item, int n_eta1, const Workspace& ws,
+                                ChunkPipe* pipe = nullptr, int buf = 0);
 inline void launch_sample(stream_t st, const ParamSet& p, size_t n, const uint8_t* rho, size_t rho_stride, int transpose,
                           const uint8_t* r, int prf_per_item, int n_eta1, const Workspace& ws) {
-    launch_sample_split(st, p, n, n, rho, rho_stride, transpose, r, prf_per_item, n_eta1, ws);
+    launch_sample_split(st, st, p, n, n, rho, rho_stride, transpose, r, prf_per_item, n_eta1, ws);
 }
-inline void launch_sample_split(stream_t st, const ParamSet& p, size_t n_xof_items, size_t n_prf_items, const uint8_t* rho,
-                                size_t rho_stride, int transpose, const uint8_t* r, int prf_per_item, int n_eta1, const Workspace& ws) {
+// the chunk loops' form: three-block kernel on `st`, leftover pass on the arithmetic stream, which is returned
+inline stream_t launch_sample_piped(stream_t st, ChunkPipe& pipe, int buf, const ParamSet& p, size_t n, const uint8_t* rho, size_t rho_stride,
+                                    int transpose, const uint8_t* r, int prf_per_item, int n_eta1, const Workspace& ws) {
+    launch_sample_split(st, nullptr, p, n, n, rho, rho_stride, transpose, r, prf_per_item, n_eta1, ws, &pipe, buf);
+    return pipe.last_arith;
+}
+inline void launch_sample_split(stream_t st, stream_t tail_st, const ParamSet& p, size_t n_xof_items, size_t n_prf_items, const uint8_t* rho,
+                                size_t rho_stride, int transpose, const uint8_t* r, int prf_per_item, int n_eta1, const Workspace& ws,
+                                ChunkPipe* pipe, int buf) {
     SampleArgs a{};
     a.n_xof = n_xof_items * (size_t)(p.k * p.k);
     a.rho = rho; a.rho_stride = rho_stride; a.K = p.k; a.transpose = transpose; a.A = ws.A;
@@ -185,17 +197,19 @@ inline void launch_sample_split(stream_t st, const ParamSet& p, size_t n_xof_ite
     a.prf_rate = ws.fips ? 136 : 168;
     zero_u32(st, ws.leftover);
     const size_t grid = a.xof_blocks + ceil_div(a.n_prf, WAVE);
-    if (grid == 0) return;
-    if (ws.ring == 128) launch("k_sample_main", k_sample_main<128>, grid, WAVE, st, a);
-    else if (ws.ring == 32) launch("k_sample_main", k_sample_main<32>, grid, WAVE, st, a);
-    else launch("k_sample_main", k_sample_main<64>, grid, WAVE, st, a);
-    if (a.n_xof == 0) return;
+    if (grid != 0) {
+        if (ws.ring == 128) launch("k_sample_main", k_sample_main<128>, grid, WAVE, st, a);
+        else if (ws.ring == 32) launch("k_sample_main", k_sample_main<32>, grid, WAVE, st, a);
+        else launch("k_sample_main", k_sample_main<64>, grid, WAVE, st, a);
+    }
+    if (pipe) tail_st = pipe->last_arith = pipe->arith_stream(buf);   // fork point: behind the three-block kernel
+    if (grid == 0 || a.n_xof == 0) return;
     // leftovers: expected 0.8 % of the sponges; the grid covers 1/16 of them and strides over the rest if ever needed
     SampleArgs t = a;
     t.list_mode = 1;
     t.n_prf = 0;
     t.xof_blocks = (unsigned)(ceil_div(a.n_xof, WAVE * 16) + 1);
-    launch("k_sample_tail", k_sample, (size_t)t.xof_blocks, WAVE, st, t);
+    launch("k_sample_tail", k_sample, (size_t)t.xof_blocks, WAVE, tail_st, t);
 }
 
 // ---- ML-KEM.KeyGen_internal (ml_kem.c:1034-1084) ; z == nullptr: K-PKE.KeyGen alone (ml_kem.c:651-769, dk = 384k-byte ŝ) ----
@@ -212,13 +226,13 @@ inline void keygen_run(stream_t st, const ParamSet& p, size_t n, const uint8_t* 
             const size_t cn = min_sz(ws.cap, hn - c0), i0 = h0 + c0;
             const int buf = pipe.begin_chunk();
             const Workspace w = ws.view(buf);
-            launch_sample(st, p, cn, ws.rho + c0 * 32, 32, /*transpose=*/0, ws.r + c0 * 32, 2 * K, 2 * K, w);
+            const stream_t ast = launch_sample_piped(st, pipe, buf, p, cn, ws.rho + c0 * 32, 32, /*transpose=*/0, ws.r + c0 * 32, 2 * K, 2 * K, w);
             if (kem)
-                launch("k_keygen", k_keygen<K, ETA1, true>, ceil_div(cn, ARITH_WAVES), WAVE * ARITH_WAVES, pipe.arith_stream(buf), cn,
+                launch("k_keygen", k_keygen<K, ETA1, true>, ceil_div(cn, ARITH_WAVES), WAVE * ARITH_WAVES, ast, cn,
                        (const uint16_t*)w.A, (const uint8_t*)w.prf, (const uint8_t*)(ws.rho + c0 * 32), ek + i0 * p.ek_len,
                        dk + i0 * dk_len);
             else
-                launch("k_keygen", k_keygen<K, ETA1, false>, ceil_div(cn, ARITH_WAVES), WAVE * ARITH_WAVES, pipe.arith_stream(buf), cn,
+                launch("k_keygen", k_keygen<K, ETA1, false>, ceil_div(cn, ARITH_WAVES), WAVE * ARITH_WAVES, ast, cn,
                        (const uint16_t*)w.A, (const uint8_t*)w.prf, (const uint8_t*)(ws.rho + c0 * 32), ek + i0 * p.ek_len,
                        dk + i0 * dk_len);
             pipe.end_chunk(buf);
@@ -246,9 +260,9 @@ inline void encaps_run(stream_t st, const ParamSet& p, size_t n, const uint8_t* 
             const uint8_t* eki = ek + i0 * p.ek_len;
             const int buf = pipe.begin_chunk();
             const Workspace w = ws.view(buf);
-            launch_sample(st, p, cn, eki + 384 * K, p.ek_len, /*transpose=*/1, r_h + c0 * 32, 2 * K + 1, K, w);
+            const stream_t ast = launch_sample_piped(st, pipe, buf, p, cn, eki + 384 * K, p.ek_len, /*transpose=*/1, r_h + c0 * 32, 2 * K + 1, K, w);
             launch("k_encrypt", k_encrypt<K, ETA1, DU, DV, false>, ceil_div(cn, ARITH_WAVES), WAVE * ARITH_WAVES,
-                   pipe.arith_stream(buf), cn, eki, (size_t)p.ek_len, m + i0 * 32, (const uint16_t*)w.A, (const uint8_t*)w.prf,
+                   ast, cn, eki, (size_t)p.ek_len, m + i0 * 32, (const uint16_t*)w.A, (const uint8_t*)w.prf,
                    c + i0 * p.c_len, (const uint8_t*)nullptr, (const uint8_t*)nullptr, (const uint8_t*)nullptr, (uint8_t*)nullptr,
                    mod_status ? mod_status + i0 : (int32_t*)nullptr, (size_t)(K * K * 256));
             pipe.end_chunk(buf);
@@ -285,9 +299,9 @@ inline void decaps_run(stream_t st, const ParamSet& p, size_t n, const uint8_t* 
             const uint8_t* dki = dk + i0 * p.dk_len;
             const int buf = pipe.begin_chunk();
             const Workspace w = ws.view(buf);
-            launch_sample(st, p, cn, dki + 768 * K, p.dk_len, /*transpose=*/1, ws.r + c0 * 32, 2 * K + 1, K, w);
+            const stream_t ast = launch_sample_piped(st, pipe, buf, p, cn, dki + 768 * K, p.dk_len, /*transpose=*/1, ws.r + c0 * 32, 2 * K + 1, K, w);
             launch("k_encrypt_cmp", k_encrypt<K, ETA1, DU, DV, true>, ceil_div(cn, ARITH_WAVES), WAVE * ARITH_WAVES,
-                   pipe.arith_stream(buf), cn, dki + 384 * K, (size_t)p.dk_len, (const uint8_t*)(ws.m + c0 * 32), (const uint16_t*)w.A,
+                   ast, cn, dki + 384 * K, (size_t)p.dk_len, (const uint8_t*)(ws.m + c0 * 32), (const uint16_t*)w.A,
                    (const uint8_t*)w.prf, (uint8_t*)nullptr, c + i0 * p.c_len, (const uint8_t*)(ws.Kp + c0 * 32),
                    (const uint8_t*)(ws.Kbar + c0 * 32), Kout + i0 * 32, (int32_t*)nullptr, (size_t)(K * K * 256));
             pipe.end_chunk(buf);
@@ -305,13 +319,13 @@ inline void encaps_shared_run(stream_t st, const ParamSet& p, size_t n, const ui
     const Workspace w = ws.view(0);
     uint8_t* h = ws.rho;                                                          // 32 bytes, unused by Encaps otherwise
     launch("k_hash_batch", k_hash_batch<0>, (size_t)1, WAVE, st, (size_t)1, ek, (unsigned)p.ek_len, (size_t)p.ek_len, h);
-    launch_sample_split(st, p, 1, 0, ek + 384 * K, p.ek_len, /*transpose=*/1, nullptr, 0, 0, w);   // A^T once
+    launch_sample_split(st, st, p, 1, 0, ek + 384 * K, p.ek_len, /*transpose=*/1, nullptr, 0, 0, w);   // A^T once
     for (size_t h0 = 0; h0 < n; h0 += ws.hcap) {
         const size_t hn = min_sz(ws.hcap, n - h0);
         launch("k_hash_g_shared", k_hash_g_shared, ceil_div(hn, WAVE), WAVE, st, hn, m + h0 * 32, (const uint8_t*)h, Kout + h0 * 32, ws.r);
         for (size_t c0 = 0; c0 < hn; c0 += ws.cap) {
             const size_t cn = min_sz(ws.cap, hn - c0), i0 = h0 + c0;
-            launch_sample_split(st, p, 0, cn, nullptr, 0, 1, ws.r + c0 * 32, 2 * K + 1, K, w);      // PRF rows per item
+            launch_sample_split(st, st, p, 0, cn, nullptr, 0, 1, ws.r + c0 * 32, 2 * K + 1, K, w);      // PRF rows per item
             launch("k_encrypt", k_encrypt<K, ETA1, DU, DV, false>, ceil_div(cn, ARITH_WAVES), WAVE * ARITH_WAVES, st, cn, ek, (size_t)0,
                    m + i0 * 32, (const uint16_t*)w.A, (const uint8_t*)w.prf, c + i0 * p.c_len, (const uint8_t*)nullptr,
                    (const uint8_t*)nullptr, (const uint8_t*)nullptr, (uint8_t*)nullptr, (int32_t*)nullptr, (size_t)0);
@@ -327,7 +341,7 @@ inline void decaps_shared_run(stream_t st, const ParamSet& p, size_t n, const ui
         launch("k_hash_batch", k_hash_batch<0>, (size_t)1, WAVE, st, (size_t)1, dk + 384 * K, (unsigned)p.ek_len, (size_t)p.dk_len, ws.rho);
         launch("k_status_fill", k_status_fill, min_sz(ceil_div(n, 256), 1024), 256u, st, n, (const uint8_t*)ws.rho, dk + 768 * K + 32, status);
     }
-    launch_sample_split(st, p, 1, 0, dk + 768 * K, p.dk_len, /*transpose=*/1, nullptr, 0, 0, w);   // A^T once (rho sits in dk.ek)
+    launch_sample_split(st, st, p, 1, 0, dk + 768 * K, p.dk_len, /*transpose=*/1, nullptr, 0, 0, w);   // A^T once (rho sits in dk.ek)
     for (size_t h0 = 0; h0 < n; h0 += ws.hcap) {
         const size_t hn = min_sz(ws.hcap, n - h0);
         const uint8_t* ch = c + h0 * p.c_len;
@@ -339,7 +353,7 @@ inline void decaps_shared_run(stream_t st, const ParamSet& p, size_t n, const ui
             launch("k_hash_decaps", k_hash_decaps<K, CLEN, false, 136>, hgrid, WAVE, st, hn, dk, ch, (const uint8_t*)ws.m, ws.Kp, ws.r, ws.Kbar, (int32_t*)nullptr, (size_t)0);
         for (size_t c0 = 0; c0 < hn; c0 += ws.cap) {
             const size_t cn = min_sz(ws.cap, hn - c0), i0 = h0 + c0;
-            launch_sample_split(st, p, 0, cn, nullptr, 0, 1, ws.r + c0 * 32, 2 * K + 1, K, w);
+            launch_sample_split(st, st, p, 0, cn, nullptr, 0, 1, ws.r + c0 * 32, 2 * K + 1, K, w);
             launch("k_encrypt_cmp", k_encrypt<K, ETA1, DU, DV, true>, ceil_div(cn, ARITH_WAVES), WAVE * ARITH_WAVES, st, cn, dk + 384 * K,
                    (size_t)0, (const uint8_t*)(ws.m + c0 * 32), (const uint16_t*)w.A, (const uint8_t*)w.prf, (uint8_t*)nullptr, c + i0 * p.c_len,
                    (const uint8_t*)(ws.Kp + c0 * 32), (const uint8_t*)(ws.Kbar + c0 * 32), Kout + i0 * 32, (int32_t*)nullptr, (size_t)0);
@@ -437,16 +451,6 @@ inline size_t poly_grid(size_t n) {
     const size_t cap = 256 * 16;   // 256 CUs x a few workgroups, grid-stride for the rest
     return g < cap ? g : cap;
 }
-// two polynomials per wave and iteration, all in registers (mlkem_rntt.hpp); MLKEM_NTT_LDS=1 selects the one-polynomial-
-// per-wave LDS form the K-PKE kernels use (A/B measurements)
-inline bool ntt_use_lds() {
-#ifdef MLKEM_EMU
-    const bool v = getenv("MLKEM_NTT_LDS") && atoi(getenv("MLKEM_NTT_LDS")) == 1;   // the tests flip it between calls
-#else
-    static const bool v = getenv("MLKEM_NTT_LDS") && atoi(getenv("MLKEM_NTT_LDS")) == 1;
-#endif
-    return v;
-}
 // persistent grid of the register NTT (measured with tools/ntt_ubench.hip, profiles/r02_ntt_design.txt: 12288-16384
 // workgroups are best, 2^20 polynomials = 5.3 wave-iterations each; below 2048 the tail dominates; MLKEM_NTT_GRID overrides)
 inline size_t ntt_grid_cap() {
@@ -457,12 +461,8 @@ inline size_t ntt_grid_cap() {
     }();
     return v;
 }
+// four polynomials per wave and iteration, all in registers (mlkem_rntt.hpp)
 inline void ntt_launch(stream_t st, bool inverse, size_t n, const uint16_t* in, uint16_t* out) {
-    if (ntt_use_lds()) {
-        if (inverse) launch("k_intt_batch", k_ntt_batch<true>, poly_grid(n), WAVE * ARITH_WAVES, st, n, in, out);
-        else launch("k_ntt_batch", k_ntt_batch<false>, poly_grid(n), WAVE * ARITH_WAVES, st, n, in, out);
-        return;
-    }
     size_t grid = ceil_div(ceil_div(n, 4), RNTT_WAVES);
     const size_t cap = ntt_grid_cap();
     if (grid > cap) grid = cap;

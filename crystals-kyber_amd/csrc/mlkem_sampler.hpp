@@ -75,6 +75,9 @@ __device__ __forceinline__ void ring_flush_t(const int16_t* ring, uint16_t* A, s
 // cross-lane traffic, no fences; the scattered 16-byte stores (one 64-byte segment per lane, completed by consecutive
 // instructions) ride on the otherwise idle memory pipe, whereas the cooperative variant above spends ~45 VALU/DS
 // instructions per flush point in a VALU-bound kernel.  MLKEM_SAMPLER_COOP_FLUSH=1 selects the cooperative variant.
+#ifndef MLKEM_EXP_A384
+#define MLKEM_EXP_A384 0
+#endif
 #ifndef MLKEM_SAMPLER_COOP_FLUSH
 #define MLKEM_SAMPLER_COOP_FLUSH 0
 #endif
@@ -84,6 +87,9 @@ __device__ __forceinline__ void ring_flush_own(const char* ringb, uint16_t* A, s
     if ((pos - flushed >= 2u * R::CHUNK) && (g < n_xof)) {
         const char* src = ringb + (flushed & (2u * R::N - 1u));
         char* dst = reinterpret_cast<char*>(A + g * 256) + flushed;
+#if MLKEM_EXP_A384   // TIMING EXPERIMENT ONLY (wrong results): 384 instead of 512 bytes per polynomial reach HBM, the upper
+        if (flushed < 384u)   // bound of what a 12-bit packed matrix could save (no pack / unpack instructions are paid here)
+#endif
 #pragma unroll
         for (int q = 0; q < R::CHUNK / 8; q++)
             reinterpret_cast<uint4*>(dst)[q] = reinterpret_cast<const uint4*>(src)[q];

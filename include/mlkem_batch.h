@@ -119,9 +119,15 @@ int mlkem_pke_decrypt_dev(mlkem_ctx* ctx, int param_set, size_t n, const uint8_t
                           void* stream);
 
 /* ---- batched primitives, device pointers (BASELINE config 2 and component parity tests) ------------ */
-/* replaces NTT(f)              ml_kem.c:287-329 ; in/out : n x uint16[256], coefficients in [0, q) */
+/* replaces NTT(f)              ml_kem.c:287-329 ; in/out : n x uint16[256].  Inputs are taken mod 2^12 like the reference's
+ * `union integer.t`; the result is bit-identical to the reference for EVERY 12-bit input: coefficients in [0, q) (FIPS 203's
+ * domain, all the reference's own call sites) give the canonical transform, and coefficients >= q take an exact integer
+ * path that reproduces the reference's non-modular step (ml_kem.c:317 stores f[j] - t unreduced), whose outputs can stay
+ * >= q (NTT of 4095 x^0 has 4095 at index 254).  f_hat may not alias f partially (equal pointers are fine). */
 int mlkem_ntt_dev(mlkem_ctx* ctx, size_t n, const uint16_t* f, uint16_t* f_hat, void* stream);
-/* replaces InverseNTT(fh)      ml_kem.c:336-384 */
+/* replaces InverseNTT(fh)      ml_kem.c:336-384 ; coefficients in [0, q).  For coefficients >= q the reference's own result
+ * is undefined (ml_kem.c:364-367 overflows a signed int: its -O0 and -O2 builds disagree); this entry then returns the
+ * inverse transform of the input reduced mod q. */
 int mlkem_intt_dev(mlkem_ctx* ctx, size_t n, const uint16_t* f_hat, uint16_t* f, void* stream);
 /* replaces MultiplyNTTs(f, g)  ml_kem.c:415-442 ; inputs may be any 12-bit value (as ByteDecode_12 yields) */
 int mlkem_multiply_ntts_dev(mlkem_ctx* ctx, size_t n, const uint16_t* f_hat, const uint16_t* g_hat, uint16_t* h_hat, void* stream);

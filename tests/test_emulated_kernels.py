@@ -335,13 +335,12 @@ def test_emu_fcanon_floor_exhaustive(emu):
     assert emu.emu_fcanon_floor_exhaustive() == 0
 
 
-def test_emu_register_ntt_two_polys_per_wave(emu, oracle, golden_npz):
-    """k_ntt2_batch (mlkem_rntt.hpp: two polynomials per wave in registers, permlane swaps + DPP butterflies, emulated with
-    shuffles): every batch size parity (odd n leaves half a wave idle), raw 12-bit inputs, extreme-magnitude inputs that
-    drive the lazy bounds to their limits, and the LDS form of the same transform selected by MLKEM_NTT_LDS=1."""
-    import os
+def test_emu_register_ntt_four_polys_per_wave(emu, oracle, golden_npz):
+    """k_ntt4_batch (mlkem_rntt.hpp: four polynomials per wave in registers, DPP cross-lane butterflies, emulated with
+    shuffles): every batch size mod 4 (rows beyond n idle), raw 12-bit inputs, extreme-magnitude inputs that
+    drive the lazy bounds to their limits."""
     rng = np.random.default_rng(5)
-    cases = [rng.integers(0, 3329, (n, 256)).astype(np.uint16) for n in (1, 2, 3, 9)]
+    cases = [rng.integers(0, 3329, (n, 256)).astype(np.uint16) for n in (1, 2, 3, 4, 5, 7, 9)]
     cases.append(rng.integers(0, 4096, (4, 256)).astype(np.uint16))                       # non-canonical 12-bit values
     ext = np.zeros((6, 256), np.uint16)
     ext[0] = 4095; ext[1] = 3328; ext[2, ::2] = 4095; ext[3, 1::2] = 4095
@@ -355,13 +354,9 @@ def test_emu_register_ntt_two_polys_per_wave(emu, oracle, golden_npz):
         # forward: the reference's own (non-modular, ml_kem.c:317) behaviour on coefficients >= q is reproduced exactly;
         # inverse: inputs >= q are outside the contract (the reference overflows a signed int there): reduced first
         want_f, want_i = oracle.ntt(a & 0xFFF).reshape(a.shape), oracle.intt((a & 0xFFF) % 3329).reshape(a.shape)
-        for lds in ("0", "1"):
-            os.environ["MLKEM_NTT_LDS"] = lds
-            out = np.zeros_like(a)
-            emu.emu_ntt(0, C.c_size_t(a.shape[0]), p16(a), p16(out))
-            if lds == "0" or (a & 0xFFF).max() < 3329:      # the LDS form has no exact path for coefficients >= q
-                assert (out == want_f).all(), (a.shape, lds)
-            emu.emu_ntt(1, C.c_size_t(a.shape[0]), p16(a), p16(out))
-            assert (out == want_i).all(), (a.shape, lds)
-    os.environ.pop("MLKEM_NTT_LDS", None)
+        out = np.zeros_like(a)
+        emu.emu_ntt(0, C.c_size_t(a.shape[0]), p16(a), p16(out))
+        assert (out == want_f).all(), a.shape
+        emu.emu_ntt(1, C.c_size_t(a.shape[0]), p16(a), p16(out))
+        assert (out == want_i).all(), a.shape
     assert want_f[1, 254] == 4095

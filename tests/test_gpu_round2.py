@@ -66,14 +66,14 @@ def test_selftest_counter_actually_counts(pkg, eng):
     assert lib.mlkem_selftest(eng._ctx, 3, C.byref(v)) == 0 and v.value == 0
 
 
-# ---- the register NTT (two polynomials per wave, permlane swaps + DPP butterflies) on the real lanes ---------------------
+# ---- the register NTT (four polynomials per wave, DPP cross-lane butterflies) on the real lanes -------------------------
 def test_register_ntt_extremes_and_reference_behaviour_above_q(pkg, eng, torch, oracle):
-    """mlkem_rntt.hpp on gfx950: v_permlane32/16_swap and v_fmac_f32_dpp only exist on the device, so the layouts are
+    """mlkem_rntt.hpp on gfx950: v_fmac_f32_dpp (quad_perm, row_half_mirror, row_ror) only exists on the device, so the layouts are
     checked here against the oracle on inputs built to hit every lane / register position and the lazy bounds: unit
     vectors at every coefficient index, all-maximum polynomials, alternating extremes, random canonical and random raw
     12-bit polynomials (forward: the reference's non-modular arithmetic above q is reproduced exactly, e.g. NTT of
     4095 x^0 has 4095 at index 254; inverse: inputs >= q are reduced first, the reference's result there is
-    compiler-dependent), odd and even batch sizes, and the LDS form of the same transform."""
+    compiler-dependent), every batch size mod 4."""
     rng = np.random.default_rng(77)
     unit = np.zeros((256, 256), np.uint16)
     unit[np.arange(256), np.arange(256)] = 3328
@@ -83,7 +83,7 @@ def test_register_ntt_extremes_and_reference_behaviour_above_q(pkg, eng, torch, 
         ext[4 + b] = np.where(np.arange(256) & (1 << (2 * b + 1)), 3328, 0)
     one = np.zeros((1, 256), np.uint16)
     one[0, 0] = 4095
-    cases = [unit, unit[:255], ext, one, rng.integers(0, 3329, (1001, 256)).astype(np.uint16),
+    cases = [unit, unit[:255], unit[:254], unit[:253], ext, one, rng.integers(0, 3329, (1001, 256)).astype(np.uint16),
              rng.integers(0, 4096, (1000, 256)).astype(np.uint16)]
     for a in cases:
         da = dev(torch, a.view(np.int16))
