@@ -124,7 +124,7 @@ int mlkem_ctx_create(mlkem_ctx** out, int device, size_t chunk_items) {
         if (v > 0) hn = (size_t)v;
     }
     if (hn < n) hn = n;
-    if (const char* e = getenv("MLKEM_RING")) { const int r = atoi(e); c->ws.ring = (r == 128 || r == 32) ? r : 64; }
+    if (const char* e = getenv("MLKEM_RING")) { const int r = atoi(e); c->ws.ring = (r == 128 || r == 64 || r == 32) ? r : 0; }
     // Sampler/arithmetic overlap on a helper stream is opt-in (MLKEM_OVERLAP=1): measured on MI355X it does not pay,
     // because both kernel families are VALU-issue-bound (profiles/r01_overlap.txt); it doubles the chunk scratch.
     const char* ov = getenv("MLKEM_OVERLAP");

@@ -118,7 +118,8 @@ struct Workspace {
     event_t ev_sample[2] = {nullptr, nullptr}, ev_free[2] = {nullptr, nullptr};
     size_t cap = 0;    // chunk capacity (items) of A / prf / leftover
     size_t hcap = 0;   // h-chunk capacity (items) of the 32-byte arrays
-    int ring = 64;     // sampler LDS ring size (32, 64 or 128 coefficients per lane); measured equal on MI355X (power-capped)
+    int ring = 0;      // sampler staging: 0 = linear buffer + EXEC-masked acceptance (default), or an LDS ring of 32 / 64 / 128
+                       // coefficients per lane (the r01 forms, kept for A/B measurements: MLKEM_RING)
     int fips = 0;      // 0: bit-identical to the reference (PRF, J on SHAKE128; no-op modulus check)
                        // 1: FIPS 203 conformant (PRF, J on SHAKE256; encaps reports status -4 for t-hat coefficients >= q)
     Workspace view(int b) const {
@@ -200,7 +201,8 @@ inline void launch_sample_split(stream_t st, stream_t tail_st, const ParamSet& p
     if (grid != 0) {
         if (ws.ring == 128) launch("k_sample_main", k_sample_main<128>, grid, WAVE, st, a);
         else if (ws.ring == 32) launch("k_sample_main", k_sample_main<32>, grid, WAVE, st, a);
-        else launch("k_sample_main", k_sample_main<64>, grid, WAVE, st, a);
+        else if (ws.ring == 64) launch("k_sample_main", k_sample_main<64>, grid, WAVE, st, a);
+        else launch("k_sample_main", k_sample_main<0>, grid, WAVE, st, a);
     }
     if (pipe) tail_st = pipe->last_arith = pipe->arith_stream(buf);   // fork point: behind the three-block kernel
     if (grid == 0 || a.n_xof == 0) return;

@@ -134,10 +134,68 @@ __device__ __forceinline__ void ring_flush_own(const char* ringb, uint16_t* A, s
     if constexpr (R::N == 32) { MLKEM_BLOCK32(T) }        \
     else { MLKEM_BLOCK(T) }
 
+// ---- RING_N = 0: linear staging buffer + EXEC-masked acceptance (the default) ----------------------------------------
+// The ring above pays v_cmp + v_cndmask + v_add for the position and v_and + v_add for the wrapped address of every one
+// of the 336 candidates (7.2 issue units each, 15 % of the permutation's).  Here a lane's `pos` IS the LDS byte address of
+// its next coefficient in a linear 144-byte buffer, and a candidate is accepted by masking: v_cmpx_gt_u32 leaves EXEC =
+// lanes whose candidate is < q, the ds_write_b16 and the v_add_u32 pos += 2 run under that mask, s_mov_b64 restores EXEC
+// (4.3 units: one VOPC + one plain VALU; the DS and scalar instructions issue on their own ports).  Twice per block the
+// complete 16-byte pieces go to HBM and the < 16-byte remainder moves to the front of the buffer (at most 16 + 112 bytes
+// are ever staged: 56 candidates between flush points).
+constexpr int LIN_STRIDE = 144;   // bytes per lane: 9 x 16, rows 16-byte aligned, 36-dword skew
+#ifdef MLKEM_EMU
+#define MLKEM_LIN_ACCEPT(lds0, pos, d) { if ((d) < (uint32_t)KQ) { *reinterpret_cast<int16_t*>((lds0) + (pos)) = (int16_t)(d); (pos) += 2u; } }
+#define MLKEM_LIN_ACCEPT_LIM(lds0, pos, d, lim) { if ((d) < (uint32_t)KQ && (pos) < (lim)) { *reinterpret_cast<int16_t*>((lds0) + (pos)) = (int16_t)(d); (pos) += 2u; } }
+#else
+// all 64 lanes are active in the XOF role (sponges beyond n_xof are clamped duplicates), so EXEC is restored to -1
+#define MLKEM_LIN_ACCEPT(lds0, pos, d)                                              \
+    asm volatile("v_cmpx_gt_u32 vcc, 0xd01, %1\n\t"                                 \
+                 "ds_write_b16 %0, %1\n\t"                                          \
+                 "v_add_u32 %0, 2, %0\n\t"                                          \
+                 "s_mov_b64 exec, -1"                                               \
+                 : "+v"(pos) : "v"(d) : "vcc", "memory")
+#define MLKEM_LIN_ACCEPT_LIM(lds0, pos, d, lim)                                     \
+    asm volatile("v_cmpx_gt_u32 vcc, 0xd01, %1\n\t"                                 \
+                 "v_cmpx_gt_u32 vcc, %2, %0\n\t"                                    \
+                 "ds_write_b16 %0, %1\n\t"                                          \
+                 "v_add_u32 %0, 2, %0\n\t"                                          \
+                 "s_mov_b64 exec, -1"                                               \
+                 : "+v"(pos) : "v"(d), "v"(lim) : "vcc", "memory")
+#endif
+// the 8 candidates of a 12-byte group of the squeezed block (ml_kem.c:208-219), FIRST..LAST-1 of its 4 triples
+#define MLKEM_LG(ACC, W0, FIRST, LAST)                                                                         \
+    {                                                                                                           \
+        const uint32_t w0 = keccak_word<W0>(s), w1 = keccak_word<W0 + 1>(s), w2 = keccak_word<W0 + 2>(s);       \
+        if (FIRST <= 0 && LAST > 0) { ACC(w0 & 0xFFFu) ACC((w0 >> 12) & 0xFFFu) }                               \
+        if (FIRST <= 1 && LAST > 1) { ACC(__builtin_amdgcn_alignbit(w1, w0, 24) & 0xFFFu) ACC((w1 >> 4) & 0xFFFu) } \
+        if (FIRST <= 2 && LAST > 2) { ACC((w1 >> 16) & 0xFFFu) ACC(__builtin_amdgcn_alignbit(w2, w1, 28) & 0xFFFu) } \
+        if (FIRST <= 3 && LAST > 3) { ACC((w2 >> 8) & 0xFFFu) ACC(w2 >> 20) }                                   \
+    }
+#define MLKEM_LBLOCK(ACC, FLUSH)                                                                               \
+    MLKEM_LG(ACC, 0, 0, 4) MLKEM_LG(ACC, 3, 0, 4) MLKEM_LG(ACC, 6, 0, 4) MLKEM_LG(ACC, 9, 0, 4)                 \
+    MLKEM_LG(ACC, 12, 0, 4) MLKEM_LG(ACC, 15, 0, 4) MLKEM_LG(ACC, 18, 0, 4)                                     \
+    FLUSH                                                                                                       \
+    MLKEM_LG(ACC, 21, 0, 4) MLKEM_LG(ACC, 24, 0, 4) MLKEM_LG(ACC, 27, 0, 4) MLKEM_LG(ACC, 30, 0, 4)             \
+    MLKEM_LG(ACC, 33, 0, 4) MLKEM_LG(ACC, 36, 0, 4) MLKEM_LG(ACC, 39, 0, 4)                                     \
+    FLUSH
+
+// complete 16-byte pieces of the lane's staging buffer -> HBM (the polynomial's next bytes), remainder to the front.
+// `buf` = the lane's buffer, `pos0` = its LDS byte address; pos / lim are LDS addresses, flushed counts bytes in HBM.
+__device__ __forceinline__ void lin_flush(char* buf, uint32_t pos0, uint32_t& pos, uint32_t& lim, uint32_t& flushed, char* dst_poly, bool valid) {
+    const uint32_t n16 = (pos - pos0) >> 4;
+#pragma unroll
+    for (uint32_t i = 0; i < 8; i++)
+        if (i < n16 && valid) *reinterpret_cast<uint4*>(dst_poly + flushed + 16u * i) = *reinterpret_cast<const uint4*>(buf + 16u * i);
+    if (n16) *reinterpret_cast<uint4*>(buf) = *reinterpret_cast<const uint4*>(buf + 16u * n16);
+    pos -= 16u * n16;
+    lim -= 16u * n16;
+    flushed += 16u * n16;
+}
+
 template <int RING_N>
-__global__ void __launch_bounds__(WAVE, (RING_N == 32 ? MLKEM_KECCAK_MINWAVES : RING_N == 64 ? 4 : 2)) k_sample_main(SampleArgs a) {   // LDS caps rings 64 / 128 at 4 / 2 waves per SIMD
-    using R = RingCfg<RING_N>;
-    static_assert(WAVE * R::STRIDE * 2 >= 32 * 33 * 4, "the PRF role stages 32 rows x 33 dwords in the ring");
+__global__ void __launch_bounds__(WAVE, (RING_N == 32 ? MLKEM_KECCAK_MINWAVES : RING_N == 128 ? 2 : 4)) k_sample_main(SampleArgs a) {   // LDS caps rings 0 / 64 / 128 at 4 / 4 / 2 waves per SIMD
+    using R = RingCfg<RING_N == 0 ? 64 : RING_N>;
+    static_assert(WAVE * R::STRIDE * 2 >= 32 * 33 * 4 && (RING_N != 0 || R::STRIDE * 2 >= LIN_STRIDE), "the PRF role stages 32 rows x 33 dwords in the ring");
     __shared__ __attribute__((aligned(16))) int16_t ring[WAVE * R::STRIDE];
     const int l = lane_id();
     KeccakState s;
@@ -150,21 +208,49 @@ __global__ void __launch_bounds__(WAVE, (RING_N == 32 ? MLKEM_KECCAK_MINWAVES : 
         const unsigned e = (unsigned)(gc - item * kk), ra = e / (unsigned)a.K, cb = e - ra * (unsigned)a.K;
         load32(a.rho, a.rho_stride, item, seed);
         const unsigned i0 = a.transpose ? ra : cb, i1 = a.transpose ? cb : ra;
-        char* ringb = reinterpret_cast<char*>(ring + l * R::STRIDE);   // this lane's ring
-        uint32_t pos = 0, flushed = 0;                                 // bytes: 2 x accepted / flushed coefficients
+        char* ringb = reinterpret_cast<char*>(ring + l * R::STRIDE);   // this lane's ring / staging buffer
         keccak_zero(s);
         MLKEM_SET_WORDS8(s, 0, seed)
         keccak_xor_byte<32>(s, i0);
         keccak_xor_byte<33>(s, i1);
         keccak_xor_byte<34>(s, 0x1F);
         keccak_xor_byte<167>(s, 0x80);
-        keccak_f1600(s);
-        MLKEM_SQUEEZE(MLKEM_T_FAST)
-        keccak_f1600(s);
-        MLKEM_SQUEEZE(MLKEM_T_FAST)
-        keccak_f1600(s);
-        MLKEM_SQUEEZE(MLKEM_T_GUARD)
-        if (pos < 512u && g < a.n_xof) {   // ~0.8 % of sponges: finished by k_sample in list mode
+        bool unfinished;
+        if constexpr (RING_N == 0) {
+            char* lbuf = reinterpret_cast<char*>(ring) + l * LIN_STRIDE;
+#ifdef MLKEM_EMU
+            char* const lds0 = lbuf;                 // emulator: positions are offsets into the lane's own buffer
+            const uint32_t pos0 = 0;
+#else
+            const uint32_t pos0 = (uint32_t)reinterpret_cast<uintptr_t>(lbuf);   // low 32 bits of a generic LDS address = the LDS byte address
+#endif
+            uint32_t pos = pos0, lim = pos0 + 512u, flushed = 0;   // lim: address at which the 256th coefficient would land (moves with the flushes)
+            char* dst_poly = reinterpret_cast<char*>(a.A + gc * 256);
+            const bool valid = g < a.n_xof;
+#define MLKEM_ACC_FAST(d) { const uint32_t dd = (d); MLKEM_LIN_ACCEPT(lds0, pos, dd); }
+#define MLKEM_ACC_LIM(d) { const uint32_t dd = (d); MLKEM_LIN_ACCEPT_LIM(lds0, pos, dd, lim); }
+#define MLKEM_LFLUSH { wave_lds_fence(); lin_flush(lbuf, pos0, pos, lim, flushed, dst_poly, valid); wave_lds_fence(); }
+            keccak_f1600(s);
+            MLKEM_LBLOCK(MLKEM_ACC_FAST, MLKEM_LFLUSH)     // blocks 1 and 2 cannot complete a polynomial (2 x 112 < 256): no limit test
+            keccak_f1600(s);
+            MLKEM_LBLOCK(MLKEM_ACC_FAST, MLKEM_LFLUSH)
+            keccak_f1600(s);
+            MLKEM_LBLOCK(MLKEM_ACC_LIM, MLKEM_LFLUSH)
+#undef MLKEM_ACC_FAST
+#undef MLKEM_ACC_LIM
+#undef MLKEM_LFLUSH
+            unfinished = flushed < 512u;
+        } else {
+            uint32_t pos = 0, flushed = 0;                                 // bytes: 2 x accepted / flushed coefficients
+            keccak_f1600(s);
+            MLKEM_SQUEEZE(MLKEM_T_FAST)
+            keccak_f1600(s);
+            MLKEM_SQUEEZE(MLKEM_T_FAST)
+            keccak_f1600(s);
+            MLKEM_SQUEEZE(MLKEM_T_GUARD)
+            unfinished = pos < 512u;
+        }
+        if (unfinished && g < a.n_xof) {   // ~0.8 % of sponges: finished by k_sample in list mode
             const uint32_t idx = atomicAdd(&a.leftover[0], 1u);
             a.leftover[1 + idx] = (uint32_t)g;
         }

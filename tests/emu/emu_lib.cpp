@@ -10,7 +10,7 @@
 using namespace mlkem;
 
 static size_t g_cap = 0, g_hcap = 0;
-static int g_ring = 64, g_fips = 0;
+static int g_ring = 0, g_fips = 0;
 
 static void* xalloc(size_t bytes) { return aligned_alloc(64, (bytes + 127) / 64 * 64); }
 
@@ -52,7 +52,7 @@ static long compress_f_mismatches() {
 }
 
 extern "C" {
-void emu_config(size_t cap, size_t hcap, int ring) { g_cap = cap; g_hcap = hcap; g_ring = (ring == 128 || ring == 32) ? ring : 64; }
+void emu_config(size_t cap, size_t hcap, int ring) { g_cap = cap; g_hcap = hcap; g_ring = (ring == 128 || ring == 64 || ring == 32) ? ring : 0; }
 void emu_conformance(int fips) { g_fips = fips != 0; }
 int emu_keygen(int set, size_t n, const uint8_t* d, const uint8_t* z, uint8_t* ek, uint8_t* dk) {
     Workspace ws = make_ws(n);

@@ -156,7 +156,7 @@ def test_emu_codec_primitives(emu, oracle, golden_npz, d):
 def test_emu_shared_key_batches(emu, oracle, pset):
     """One key for the whole batch: same bytes as the per-item path on the replicated key (oracle), incl. implicit
     rejection and the once-per-call dk hash check; chunk loops crossed (cap 3, hcap 7, 17 items)."""
-    emu.emu_config(C.c_size_t(3), C.c_size_t(7), 64)
+    emu.emu_config(C.c_size_t(3), C.c_size_t(7), 0)
     try:
         ekl, dkl, cl = SIZES[pset]
         n = 17
@@ -177,7 +177,7 @@ def test_emu_shared_key_batches(emu, oracle, pset):
         assert emu.emu_decaps_shared(pset, C.c_size_t(n), p8(dkb), p8(cb), p8(Kd), st.ctypes.data_as(C.POINTER(C.c_int32))) == 0
         assert (st == -5).all()
     finally:
-        emu.emu_config(C.c_size_t(0), C.c_size_t(0), 64)
+        emu.emu_config(C.c_size_t(0), C.c_size_t(0), 0)
 
 
 @pytest.mark.parametrize("pset", (512, 768, 1024))
@@ -229,7 +229,7 @@ def test_emu_full_wave_hash_kernels_take_the_dma_staging(emu, oracle, pset):
         assert not (Kd[i] == K[i]).all()
 
 
-@pytest.mark.parametrize("ring", (32, 64, 128))
+@pytest.mark.parametrize("ring", (0, 32, 64, 128))   # 0 = linear staging buffer (default), else the LDS ring forms
 def test_emu_matrix_sampler_with_leftover_pass(emu, oracle, ring):
     """Production SampleNTT path: three-block main kernel + general kernel over the leftover list.  With 576
     sponges about 0.8 % (4-5) need a 4th squeeze block; the test requires that the leftover path was taken."""
@@ -238,7 +238,7 @@ def test_emu_matrix_sampler_with_leftover_pass(emu, oracle, ring):
     rho = seeds("emu-rho", n, 31 + ring)
     A = np.zeros((n, k * k, 256), np.uint16)
     left = emu.emu_sample_matrix(k, C.c_size_t(n), p8(rho), 1, p16(A))
-    emu.emu_config(C.c_size_t(0), C.c_size_t(0), 64)
+    emu.emu_config(C.c_size_t(0), C.c_size_t(0), 0)
     assert left >= 1, "seed set must exercise the leftover list"
     for i in range(n):
         for a in range(k):
@@ -250,7 +250,7 @@ def test_emu_matrix_sampler_with_leftover_pass(emu, oracle, ring):
 
 def test_emu_chunk_and_hchunk_loops(emu, oracle):
     """cap = 3 items per chunk, hcap = 7 items per h-chunk, 17 items: every loop boundary is crossed."""
-    emu.emu_config(C.c_size_t(3), C.c_size_t(7), 64)
+    emu.emu_config(C.c_size_t(3), C.c_size_t(7), 0)
     try:
         pset, n = 768, 17
         ekl, dkl, cl = SIZES[pset]
@@ -270,7 +270,7 @@ def test_emu_chunk_and_hchunk_loops(emu, oracle):
         Ko, sto = oracle.decaps(pset, dk, cb)
         assert (st == 0).all() and (sto == 0).all() and (Kd == Ko).all()
     finally:
-        emu.emu_config(C.c_size_t(0), C.c_size_t(0), 64)
+        emu.emu_config(C.c_size_t(0), C.c_size_t(0), 0)
 
 
 def test_emu_raw_sponge_nist_examples_and_bit_lengths(emu, oracle, golden):

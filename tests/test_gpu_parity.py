@@ -538,7 +538,7 @@ def test_reference_primitive_symbols_through_the_shim(pkg, tmp_path, golden, gol
     assert "eta must be 2 or 3" in r.stderr and "Test Complete!" in r.stdout
 
 
-@pytest.mark.parametrize("env", ({"MLKEM_OVERLAP": "1"}, {"MLKEM_RING": "128"}, {"MLKEM_RING": "32"}, {"MLKEM_HCHUNK_ITEMS": "300"}))
+@pytest.mark.parametrize("env", ({"MLKEM_OVERLAP": "1"}, {"MLKEM_RING": "128"}, {"MLKEM_RING": "64"}, {"MLKEM_RING": "32"}, {"MLKEM_HCHUNK_ITEMS": "300"}))
 def test_engine_options_do_not_change_results(pkg, torch, oracle, env, monkeypatch):
     """Opt-in execution modes read at context creation: two-stream sampler/arithmetic overlap, the 128-coefficient
     sampler ring, small h-chunks.  Same bytes out."""
