@@ -132,20 +132,23 @@ int mlkem_ctx_create(mlkem_ctx** out, int device, size_t chunk_items) {
     const size_t nbuf = overlap ? 2 : 1;
     // carve one allocation: nbuf x (A | prf | leftover) | r | rho | m | Kp | Kbar, each 256-byte aligned
     auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
-    const size_t szA = up(n * 16 * 512), szP = up(n * 9 * 192), szL = up((n * 16 + 1) * 4), sz32 = up(hn * 32);
-    c->scratch_bytes = nbuf * (szA + szP + szL) + 5 * sz32;
+    const size_t rcap = n * 2 < 64 ? 64 : n * 2;   // resume records: 1/8 of the chunk's (up to 16 n) sponges, expected 0.8 %
+    const size_t szA = up(n * 16 * 512), szP = up(n * 9 * 192), szL = up((n * 16 + 2) * 4), szR = up(rcap * RESUME_WORDS * 4), sz32 = up(hn * 32);
+    c->scratch_bytes = nbuf * (szA + szP + szL + szR) + 5 * sz32;
     if (!hip_ok(hipMalloc(&c->scratch, c->scratch_bytes), "hipMalloc(scratch)")) {
         delete c;
         return MLKEM_ERR_ALLOC;
     }
     uint8_t* base = static_cast<uint8_t*>(c->scratch);
     for (int b = 0; b < 2; b++) {
-        uint8_t* q = base + (size_t)(b % nbuf) * (szA + szP + szL);
+        uint8_t* q = base + (size_t)(b % nbuf) * (szA + szP + szL + szR);
         c->ws.A2[b] = reinterpret_cast<uint16_t*>(q);
         c->ws.prf2[b] = q + szA;
         c->ws.leftover2[b] = reinterpret_cast<uint32_t*>(q + szA + szP);
+        c->ws.resume2[b] = reinterpret_cast<uint32_t*>(q + szA + szP + szL);
     }
-    c->ws.A = c->ws.A2[0]; c->ws.prf = c->ws.prf2[0]; c->ws.leftover = c->ws.leftover2[0];
+    c->ws.A = c->ws.A2[0]; c->ws.prf = c->ws.prf2[0]; c->ws.leftover = c->ws.leftover2[0]; c->ws.resume = c->ws.resume2[0];
+    c->ws.resume_cap = (uint32_t)rcap;
     if (overlap) {
         bool ok = hip_ok(hipStreamCreateWithFlags(&c->ws.helper, hipStreamNonBlocking), "hipStreamCreate");
         for (int b = 0; b < 2 && ok; b++)
@@ -153,7 +156,7 @@ int mlkem_ctx_create(mlkem_ctx** out, int device, size_t chunk_items) {
                  hip_ok(hipEventCreateWithFlags(&c->ws.ev_free[b], hipEventDisableTiming), "hipEventCreate");
         if (!ok) c->ws.helper = nullptr;
     }
-    c->ws.r = base + nbuf * (szA + szP + szL);
+    c->ws.r = base + nbuf * (szA + szP + szL + szR);
     c->ws.rho = c->ws.r + sz32;
     c->ws.m = c->ws.rho + sz32;
     c->ws.Kp = c->ws.m + sz32;

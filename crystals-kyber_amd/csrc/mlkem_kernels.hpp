@@ -559,6 +559,7 @@ __global__ void __launch_bounds__(WAVE) k_sponge_raw(size_t n, const uint8_t* __
 constexpr int RING = 128;                 // coefficients per lane ring
 constexpr int RING_STRIDE = RING + 8;     // int16 units: 272 B rows (16-byte aligned, 4-bank skew)
 
+constexpr int RESUME_WORDS = 52;
 struct SampleArgs {
     // XOF role
     size_t n_xof;             // number of XOF sponges
@@ -576,9 +577,14 @@ struct SampleArgs {
     int eta1;
     uint8_t* prf;             // output rows
     unsigned prf_stride;
-    // leftover list shared by k_sample_main (producer) and k_sample in list mode (consumer):
-    // leftover[0] = count, leftover[1..] = sponge indices that need more than three squeeze blocks
+    // sponges that need more than three squeeze blocks (0.8 %), handed from k_sample_main to the leftover passes:
+    //   leftover[1] = number of RESUME records in `resume` (k_sample_resume continues them from the saved sponge state)
+    //   leftover[0] = number of entries of the restart list leftover[2..] (sponge indices k_sample in list mode redoes from
+    //                 the seed: records beyond resume_cap, the ring forms of k_sample_main, and a resumed sponge that is
+    //                 still short after its fifth block, i.e. the reference's seed-mutation retry, ml_kem.c:237-242)
     uint32_t* leftover;
+    uint32_t* resume;         // records of RESUME_WORDS dwords: sponge index, accepted coefficients so far, 50 state dwords
+    uint32_t resume_cap;
     int list_mode;            // k_sample only: take the sponge indices from `leftover` (grid-stride)
     int prf_rate;             // 0 / 168: PRF on SHAKE128 like the reference (F2) ; 136: SHAKE256 (FIPS 203 mode)
 };
@@ -662,7 +668,7 @@ __global__ void __launch_bounds__(WAVE) k_sample(SampleArgs a) {
         const size_t slot = base + l;
         const bool valid = slot < limit;
         const size_t slot_c = valid ? slot : limit - 1;
-        const size_t g = a.list_mode ? (size_t)a.leftover[1 + slot_c] : slot_c;
+        const size_t g = a.list_mode ? (size_t)a.leftover[2 + slot_c] : slot_c;
         const size_t gc = g;
         uint32_t seed[8];
         unsigned i0, i1;

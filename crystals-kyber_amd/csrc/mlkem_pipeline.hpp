@@ -63,12 +63,12 @@ inline void launch(const char* label, void (*kfn)(KArgs...), size_t grid, unsign
 #endif
 }
 
-inline void zero_u32(stream_t st, uint32_t* p) {
+inline void zero_u32x2(stream_t st, uint32_t* p) {   // the two counters in front of the restart list
 #ifdef MLKEM_EMU
     (void)st;
-    *p = 0;
+    p[0] = 0; p[1] = 0;
 #else
-    (void)hipMemsetAsync(p, 0, sizeof(uint32_t), st);
+    (void)hipMemsetAsync(p, 0, 2 * sizeof(uint32_t), st);
 #endif
 }
 
@@ -93,7 +93,9 @@ inline bool param_set(int set, ParamSet& p) {
 // Scratch in HBM.  Per chunk item (worst case k = 4):
 //   A        k*k*512   sampled matrix, uint16 coefficients, natural order
 //   prf      (2k+1)*PS raw PRF output rows (PS = 192 for eta1 = 3, else 128)
-//   leftover 4*(k*k)   sponge indices needing a 4th squeeze block (+1 counter word)
+//   leftover 4*(k*k)   sponge indices needing a restart from the seed (+2 counter words)
+//   resume   208*(k*k)/8   saved sponges (index, count, Keccak state) that need a 4th squeeze block: room for 1/8 of all
+//                      sponges (expected: 0.8 %), the overflow goes to the restart list
 // Per h-chunk item: r, rho, m, Kp, Kbar : 32 bytes each.
 #ifdef MLKEM_EMU
 using event_t = void*;
@@ -109,11 +111,14 @@ struct Workspace {
     uint16_t* A = nullptr;      // current chunk buffer (set by view())
     uint8_t *prf = nullptr, *r = nullptr, *rho = nullptr, *m = nullptr, *Kp = nullptr, *Kbar = nullptr;
     uint32_t* leftover = nullptr;
+    uint32_t* resume = nullptr;
+    uint32_t resume_cap = 0;    // records `resume` has room for
     // the chunk scratch exists twice so that the sampler of chunk i+1 (caller's stream) can run while the
     // arithmetic kernel of chunk i (helper stream) still reads chunk i's matrix: ChunkPipe below
     uint16_t* A2[2] = {nullptr, nullptr};
     uint8_t* prf2[2] = {nullptr, nullptr};
     uint32_t* leftover2[2] = {nullptr, nullptr};
+    uint32_t* resume2[2] = {nullptr, nullptr};
     stream_t helper = nullptr;                        // nullptr: no overlap, everything on the caller's stream
     event_t ev_sample[2] = {nullptr, nullptr}, ev_free[2] = {nullptr, nullptr};
     size_t cap = 0;    // chunk capacity (items) of A / prf / leftover
@@ -124,7 +129,7 @@ struct Workspace {
                        // 1: FIPS 203 conformant (PRF, J on SHAKE256; encaps reports status -4 for t-hat coefficients >= q)
     Workspace view(int b) const {
         Workspace w = *this;
-        w.A = A2[b]; w.prf = prf2[b]; w.leftover = leftover2[b];
+        w.A = A2[b]; w.prf = prf2[b]; w.leftover = leftover2[b]; w.resume = resume2[b];
         return w;
     }
 };
@@ -194,9 +199,11 @@ inline void launch_sample_split(stream_t st, stream_t tail_st, const ParamSet& p
     a.r = r; a.per_item = prf_per_item; a.n_eta1 = n_eta1; a.eta1 = p.eta1; a.prf = ws.prf;
     a.prf_stride = p.eta1 == 3 ? 192 : 128;
     a.leftover = ws.leftover;
+    a.resume = ws.resume;
+    a.resume_cap = ws.resume ? ws.resume_cap : 0;
     a.list_mode = 0;
     a.prf_rate = ws.fips ? 136 : 168;
-    zero_u32(st, ws.leftover);
+    zero_u32x2(st, ws.leftover);
     const size_t grid = a.xof_blocks + ceil_div(a.n_prf, WAVE);
     if (grid != 0) {
         if (ws.ring == 128) launch("k_sample_main", k_sample_main<128>, grid, WAVE, st, a);
@@ -206,12 +213,15 @@ inline void launch_sample_split(stream_t st, stream_t tail_st, const ParamSet& p
     }
     if (pipe) tail_st = pipe->last_arith = pipe->arith_stream(buf);   // fork point: behind the three-block kernel
     if (grid == 0 || a.n_xof == 0) return;
-    // leftovers: expected 0.8 % of the sponges; the grid covers 1/16 of them and strides over the rest if ever needed
+    // leftovers: expected 0.8 % of the sponges; the grids cover 1/16 of them and stride over the rest if ever needed.
+    // First the sponges handed over with their state (one more permutation each), then the restart list (normally empty).
     SampleArgs t = a;
     t.list_mode = 1;
     t.n_prf = 0;
     t.xof_blocks = (unsigned)(ceil_div(a.n_xof, WAVE * 16) + 1);
-    launch("k_sample_tail", k_sample, (size_t)t.xof_blocks, WAVE, tail_st, t);
+    if (a.resume_cap && ws.ring == 0) launch("k_sample_tail", k_sample_resume, (size_t)t.xof_blocks, WAVE, tail_st, t);
+    if (a.resume_cap && ws.ring == 0) t.xof_blocks = (unsigned)(ceil_div(a.n_xof, WAVE * 256) + 1);
+    launch("k_sample_restart", k_sample, (size_t)t.xof_blocks, WAVE, tail_st, t);
 }
 
 // ---- ML-KEM.KeyGen_internal (ml_kem.c:1034-1084) ; z == nullptr: K-PKE.KeyGen alone (ml_kem.c:651-769, dk = 384k-byte ŝ) ----

@@ -140,7 +140,7 @@ __device__ __forceinline__ void ring_flush_own(const char* ringb, uint16_t* A, s
 // its next coefficient in a linear 144-byte buffer, and a candidate is accepted by masking: v_cmpx_gt_u32 leaves EXEC =
 // lanes whose candidate is < q, the ds_write_b16 and the v_add_u32 pos += 2 run under that mask, s_mov_b64 restores EXEC
 // (4.3 units: one VOPC + one plain VALU; the DS and scalar instructions issue on their own ports).  Twice per block the
-// complete 16-byte pieces go to HBM and the < 16-byte remainder moves to the front of the buffer (at most 16 + 112 bytes
+// complete 32-byte pieces go to HBM and the < 32-byte remainder moves to the front of the buffer (at most 30 + 112 bytes
 // are ever staged: 56 candidates between flush points).
 constexpr int LIN_STRIDE = 144;   // bytes per lane: 9 x 16, rows 16-byte aligned, 36-dword skew
 #ifdef MLKEM_EMU
@@ -179,17 +179,31 @@ constexpr int LIN_STRIDE = 144;   // bytes per lane: 9 x 16, rows 16-byte aligne
     MLKEM_LG(ACC, 33, 0, 4) MLKEM_LG(ACC, 36, 0, 4) MLKEM_LG(ACC, 39, 0, 4)                                     \
     FLUSH
 
-// complete 16-byte pieces of the lane's staging buffer -> HBM (the polynomial's next bytes), remainder to the front.
+// complete 32-byte pieces of the lane's staging buffer -> HBM (the polynomial's next bytes), remainder to the front.
+// 32 bytes = one HBM sector: flushing 16-byte pieces was measured to write 12 % more than the algorithmic bytes
+// (WRITE_SIZE 1767 MB against 1443 MB per launch: partial-sector writes), with 32-byte pieces the remainder (< 32 bytes)
+// plus the 112 bytes of 56 candidates still fit the 144-byte row.
 // `buf` = the lane's buffer, `pos0` = its LDS byte address; pos / lim are LDS addresses, flushed counts bytes in HBM.
 __device__ __forceinline__ void lin_flush(char* buf, uint32_t pos0, uint32_t& pos, uint32_t& lim, uint32_t& flushed, char* dst_poly, bool valid) {
-    const uint32_t n16 = (pos - pos0) >> 4;
+    const uint32_t n32 = (pos - pos0) >> 5;
 #pragma unroll
-    for (uint32_t i = 0; i < 8; i++)
-        if (i < n16 && valid) *reinterpret_cast<uint4*>(dst_poly + flushed + 16u * i) = *reinterpret_cast<const uint4*>(buf + 16u * i);
-    if (n16) *reinterpret_cast<uint4*>(buf) = *reinterpret_cast<const uint4*>(buf + 16u * n16);
-    pos -= 16u * n16;
-    lim -= 16u * n16;
-    flushed += 16u * n16;
+    for (uint32_t i = 0; i < 4; i++)
+        if (i < n32 && valid) {
+            const uint4 a = *reinterpret_cast<const uint4*>(buf + 32u * i), b = *reinterpret_cast<const uint4*>(buf + 32u * i + 16u);
+            *reinterpret_cast<uint4*>(dst_poly + flushed + 32u * i) = a;
+            *reinterpret_cast<uint4*>(dst_poly + flushed + 32u * i + 16u) = b;
+        }
+    if (n32) {   // remainder (< 32 bytes; < 16 when four pieces left, so that the row's 144 bytes are never exceeded)
+        const uint4 a = *reinterpret_cast<const uint4*>(buf + 32u * n32);
+        *reinterpret_cast<uint4*>(buf) = a;
+        if (n32 < 4) {
+            const uint4 b = *reinterpret_cast<const uint4*>(buf + 32u * n32 + 16u);
+            *reinterpret_cast<uint4*>(buf + 16u) = b;
+        }
+    }
+    pos -= 32u * n32;
+    lim -= 32u * n32;
+    flushed += 32u * n32;
 }
 
 template <int RING_N>
@@ -216,6 +230,7 @@ __global__ void __launch_bounds__(WAVE, (RING_N == 32 ? MLKEM_KECCAK_MINWAVES : 
         keccak_xor_byte<34>(s, 0x1F);
         keccak_xor_byte<167>(s, 0x80);
         bool unfinished;
+        uint32_t resume_cnt = 0;   // coefficients of this polynomial already in HBM when the sponge is handed over
         if constexpr (RING_N == 0) {
             char* lbuf = reinterpret_cast<char*>(ring) + l * LIN_STRIDE;
 #ifdef MLKEM_EMU
@@ -240,6 +255,11 @@ __global__ void __launch_bounds__(WAVE, (RING_N == 32 ? MLKEM_KECCAK_MINWAVES : 
 #undef MLKEM_ACC_LIM
 #undef MLKEM_LFLUSH
             unfinished = flushed < 512u;
+            if (unfinished && valid) {   // the staged remainder (< 32 bytes of coefficients, then don't-care bytes) joins the flushed part
+                *reinterpret_cast<uint4*>(dst_poly + flushed) = *reinterpret_cast<const uint4*>(lbuf);
+                *reinterpret_cast<uint4*>(dst_poly + flushed + 16u) = *reinterpret_cast<const uint4*>(lbuf + 16);
+            }
+            resume_cnt = (flushed + (pos - pos0)) >> 1;
         } else {
             uint32_t pos = 0, flushed = 0;                                 // bytes: 2 x accepted / flushed coefficients
             keccak_f1600(s);
@@ -250,9 +270,24 @@ __global__ void __launch_bounds__(WAVE, (RING_N == 32 ? MLKEM_KECCAK_MINWAVES : 
             MLKEM_SQUEEZE(MLKEM_T_GUARD)
             unfinished = pos < 512u;
         }
-        if (unfinished && g < a.n_xof) {   // ~0.8 % of sponges: finished by k_sample in list mode
-            const uint32_t idx = atomicAdd(&a.leftover[0], 1u);
-            a.leftover[1 + idx] = (uint32_t)g;
+        if (unfinished && g < a.n_xof) {   // ~0.8 % of sponges: finished by the leftover passes
+            uint32_t idx = a.resume_cap;
+            if constexpr (RING_N == 0) idx = atomicAdd(&a.leftover[1], 1u);
+            if (idx < a.resume_cap) {   // hand over the sponge as it stands: the fourth block costs one permutation there, not four
+                uint32_t* e = a.resume + (size_t)idx * RESUME_WORDS;
+                e[0] = (uint32_t)g;
+                e[1] = resume_cnt;
+#define MLKEM_SV(W) e[2 + W] = keccak_word<W>(s);
+                MLKEM_SV(0) MLKEM_SV(1) MLKEM_SV(2) MLKEM_SV(3) MLKEM_SV(4) MLKEM_SV(5) MLKEM_SV(6) MLKEM_SV(7) MLKEM_SV(8) MLKEM_SV(9)
+                MLKEM_SV(10) MLKEM_SV(11) MLKEM_SV(12) MLKEM_SV(13) MLKEM_SV(14) MLKEM_SV(15) MLKEM_SV(16) MLKEM_SV(17) MLKEM_SV(18) MLKEM_SV(19)
+                MLKEM_SV(20) MLKEM_SV(21) MLKEM_SV(22) MLKEM_SV(23) MLKEM_SV(24) MLKEM_SV(25) MLKEM_SV(26) MLKEM_SV(27) MLKEM_SV(28) MLKEM_SV(29)
+                MLKEM_SV(30) MLKEM_SV(31) MLKEM_SV(32) MLKEM_SV(33) MLKEM_SV(34) MLKEM_SV(35) MLKEM_SV(36) MLKEM_SV(37) MLKEM_SV(38) MLKEM_SV(39)
+                MLKEM_SV(40) MLKEM_SV(41) MLKEM_SV(42) MLKEM_SV(43) MLKEM_SV(44) MLKEM_SV(45) MLKEM_SV(46) MLKEM_SV(47) MLKEM_SV(48) MLKEM_SV(49)
+#undef MLKEM_SV
+            } else {
+                const uint32_t j = atomicAdd(&a.leftover[0], 1u);
+                a.leftover[2 + j] = (uint32_t)g;
+            }
         }
     } else {
         // ---------------- PRF role (ml_kem.c:496-515; SHAKE128 in the reference) ----------------
@@ -308,6 +343,49 @@ __global__ void __launch_bounds__(WAVE, (RING_N == 32 ? MLKEM_KECCAK_MINWAVES : 
                 return reinterpret_cast<uint32_t*>(a.prf + (g2 < a.n_prf ? g2 : a.n_prf - 1) * a.prf_stride);
             };
             prf_eta3_tail(s, a.prf_rate == 136 ? 136u : 168u, out_fn, mine);
+        }
+    }
+}
+
+// k_sample_resume — the fourth (and, if ever needed, fifth) squeeze block of the sponges k_sample_main handed over:
+// load the sponge state, permute, and append accepted candidates straight to the polynomial in HBM (on average a dozen
+// 2-byte stores per sponge).  One permutation instead of the four a restart from the seed costs; the pass is latency-bound
+// (one wave per CU), so this is wall time.  A sponge still short after block five follows the reference's retry
+// (ml_kem.c:221-242: 279-triple limit, seed mutation): it goes to the restart list for k_sample.
+__global__ void __launch_bounds__(WAVE) k_sample_resume(SampleArgs a) {
+    const int l = lane_id();
+    const size_t limit = (size_t)(a.leftover[1] < a.resume_cap ? a.leftover[1] : a.resume_cap);
+    for (size_t base = (size_t)blockIdx.x * WAVE; base < limit; base += (size_t)gridDim.x * WAVE) {
+        const size_t slot = base + l;
+        const bool valid = slot < limit;
+        const uint32_t* e = a.resume + (valid ? slot : limit - 1) * RESUME_WORDS;
+        const size_t g = e[0];
+        uint32_t cnt = valid ? e[1] : 256u;
+        KeccakState s;
+#define MLKEM_LD(W) keccak_word<W>(s) = e[2 + W];
+        MLKEM_LD(0) MLKEM_LD(1) MLKEM_LD(2) MLKEM_LD(3) MLKEM_LD(4) MLKEM_LD(5) MLKEM_LD(6) MLKEM_LD(7) MLKEM_LD(8) MLKEM_LD(9)
+        MLKEM_LD(10) MLKEM_LD(11) MLKEM_LD(12) MLKEM_LD(13) MLKEM_LD(14) MLKEM_LD(15) MLKEM_LD(16) MLKEM_LD(17) MLKEM_LD(18) MLKEM_LD(19)
+        MLKEM_LD(20) MLKEM_LD(21) MLKEM_LD(22) MLKEM_LD(23) MLKEM_LD(24) MLKEM_LD(25) MLKEM_LD(26) MLKEM_LD(27) MLKEM_LD(28) MLKEM_LD(29)
+        MLKEM_LD(30) MLKEM_LD(31) MLKEM_LD(32) MLKEM_LD(33) MLKEM_LD(34) MLKEM_LD(35) MLKEM_LD(36) MLKEM_LD(37) MLKEM_LD(38) MLKEM_LD(39)
+        MLKEM_LD(40) MLKEM_LD(41) MLKEM_LD(42) MLKEM_LD(43) MLKEM_LD(44) MLKEM_LD(45) MLKEM_LD(46) MLKEM_LD(47) MLKEM_LD(48) MLKEM_LD(49)
+#undef MLKEM_LD
+        uint16_t* poly = a.A + g * 256;
+#define MLKEM_RC(d) { const uint32_t dd = (d); if (dd < (uint32_t)KQ && cnt < 256u) { poly[cnt] = (uint16_t)dd; cnt++; } }
+#pragma unroll 1
+        for (int blk = 3; blk < 5; blk++) {
+            keccak_f1600(s);
+            MLKEM_LG(MLKEM_RC, 0, 0, 4) MLKEM_LG(MLKEM_RC, 3, 0, 4) MLKEM_LG(MLKEM_RC, 6, 0, 4) MLKEM_LG(MLKEM_RC, 9, 0, 4)
+            MLKEM_LG(MLKEM_RC, 12, 0, 4) MLKEM_LG(MLKEM_RC, 15, 0, 4) MLKEM_LG(MLKEM_RC, 18, 0, 4) MLKEM_LG(MLKEM_RC, 21, 0, 4)
+            MLKEM_LG(MLKEM_RC, 24, 0, 4) MLKEM_LG(MLKEM_RC, 27, 0, 4) MLKEM_LG(MLKEM_RC, 30, 0, 4) MLKEM_LG(MLKEM_RC, 33, 0, 4)
+            MLKEM_LG(MLKEM_RC, 36, 0, 4)
+            // in the fifth block the reference never uses triples 278, 279 (ml_kem.c:223-227: the 279th only trips the limit)
+            if (blk == 4) { MLKEM_LG(MLKEM_RC, 39, 0, 2) } else { MLKEM_LG(MLKEM_RC, 39, 0, 4) }
+            if (__ballot(cnt < 256u) == 0) break;
+        }
+#undef MLKEM_RC
+        if (cnt < 256u) {   // valid lanes only (the others start at 256): restart from the mutated seed, as the reference does
+            const uint32_t j = atomicAdd(&a.leftover[0], 1u);
+            a.leftover[2 + j] = (uint32_t)g;
         }
     }
 }

@@ -11,6 +11,7 @@ using namespace mlkem;
 
 static size_t g_cap = 0, g_hcap = 0;
 static int g_ring = 0, g_fips = 0;
+static int g_resume_cap = 64;   // resume records per chunk; a small value exercises the overflow into the restart list
 
 static void* xalloc(size_t bytes) { return aligned_alloc(64, (bytes + 127) / 64 * 64); }
 
@@ -24,9 +25,11 @@ static Workspace make_ws(size_t n) {
     for (int b = 0; b < 2; b++) {
         ws.A2[b] = (uint16_t*)xalloc(ws.cap * 16 * 512);
         ws.prf2[b] = (uint8_t*)xalloc(ws.cap * 9 * 192);
-        ws.leftover2[b] = (uint32_t*)xalloc((ws.cap * 16 + 1) * 4);
+        ws.leftover2[b] = (uint32_t*)xalloc((ws.cap * 16 + 2) * 4);
+        ws.resume2[b] = (uint32_t*)xalloc((size_t)g_resume_cap * RESUME_WORDS * 4 + 16);
     }
-    ws.A = ws.A2[0]; ws.prf = ws.prf2[0]; ws.leftover = ws.leftover2[0];
+    ws.resume_cap = (uint32_t)g_resume_cap;
+    ws.A = ws.A2[0]; ws.prf = ws.prf2[0]; ws.leftover = ws.leftover2[0]; ws.resume = ws.resume2[0];
     ws.r = (uint8_t*)xalloc(ws.hcap * 32);
     ws.rho = (uint8_t*)xalloc(ws.hcap * 32);
     ws.m = (uint8_t*)xalloc(ws.hcap * 32);
@@ -35,7 +38,7 @@ static Workspace make_ws(size_t n) {
     return ws;
 }
 static void free_ws(Workspace& ws) {
-    for (int b = 0; b < 2; b++) { free(ws.A2[b]); free(ws.prf2[b]); free(ws.leftover2[b]); }
+    for (int b = 0; b < 2; b++) { free(ws.A2[b]); free(ws.prf2[b]); free(ws.leftover2[b]); free(ws.resume2[b]); }
     free(ws.r); free(ws.rho); free(ws.m); free(ws.Kp); free(ws.Kbar);
 }
 
@@ -54,6 +57,7 @@ static long compress_f_mismatches() {
 extern "C" {
 void emu_config(size_t cap, size_t hcap, int ring) { g_cap = cap; g_hcap = hcap; g_ring = (ring == 128 || ring == 64 || ring == 32) ? ring : 0; }
 void emu_conformance(int fips) { g_fips = fips != 0; }
+void emu_resume_cap(int cap) { g_resume_cap = cap < 0 ? 0 : cap; }
 int emu_keygen(int set, size_t n, const uint8_t* d, const uint8_t* z, uint8_t* ek, uint8_t* dk) {
     Workspace ws = make_ws(n);
     int rc = keygen_dispatch(nullptr, set, n, d, z, ek, dk, ws);
@@ -125,7 +129,9 @@ int emu_sample_matrix(int k, size_t n, const uint8_t* rho, int transpose, uint16
     for (size_t i = 0; i < n * 32; i++) r[i] = (uint8_t)i;
     launch_sample(nullptr, p, n, rho, 32, transpose, r, 2 * k + 1, k, ws.view(0));
     memcpy(A_out, ws.A, n * (size_t)(k * k) * 512);
-    int left = (int)ws.leftover[0];
+    // low half: sponges that needed a 4th block (leftover[1] counts every hand-over attempt of the linear form; the ring forms
+    // only know the restart list); high half: restarts from the seed
+    int left = (int)(ws.leftover[1] ? ws.leftover[1] : ws.leftover[0]) | ((int)ws.leftover[0] << 16);
     free(r);
     free_ws(ws);
     return left;

@@ -229,17 +229,26 @@ def test_emu_full_wave_hash_kernels_take_the_dma_staging(emu, oracle, pset):
         assert not (Kd[i] == K[i]).all()
 
 
-@pytest.mark.parametrize("ring", (0, 32, 64, 128))   # 0 = linear staging buffer (default), else the LDS ring forms
-def test_emu_matrix_sampler_with_leftover_pass(emu, oracle, ring):
-    """Production SampleNTT path: three-block main kernel + general kernel over the leftover list.  With 576
-    sponges about 0.8 % (4-5) need a 4th squeeze block; the test requires that the leftover path was taken."""
+@pytest.mark.parametrize("ring,resume_cap", ((0, 64), (0, 2), (0, 0), (32, 64), (64, 64), (128, 64)))
+def test_emu_matrix_sampler_with_leftover_pass(emu, oracle, ring, resume_cap):
+    """Production SampleNTT path: three-block main kernel + the leftover passes.  With 576 sponges about 0.8 % (4-5) need
+    a 4th squeeze block; the test requires that the leftover path was taken.  ring 0 (default) = linear staging buffer,
+    leftovers handed over with their sponge state (k_sample_resume); a small resume capacity pushes the overflow (or, with
+    capacity 0, everything) onto the restart list that k_sample redoes from the seed, as the ring forms always do."""
     emu.emu_config(C.c_size_t(0), C.c_size_t(0), ring)
+    emu.emu_resume_cap(resume_cap)
     k, n = 3, 64
     rho = seeds("emu-rho", n, 31 + ring)
     A = np.zeros((n, k * k, 256), np.uint16)
     left = emu.emu_sample_matrix(k, C.c_size_t(n), p8(rho), 1, p16(A))
     emu.emu_config(C.c_size_t(0), C.c_size_t(0), 0)
-    assert left >= 1, "seed set must exercise the leftover list"
+    emu.emu_resume_cap(64)
+    total, restarted = left & 0xFFFF, left >> 16
+    assert total >= 2, "seed set must exercise the leftover passes"
+    if ring == 0:
+        assert restarted == max(0, total - resume_cap), (total, restarted)    # records beyond the capacity restart from the seed
+    else:
+        assert restarted == total
     for i in range(n):
         for a in range(k):
             for b in range(k):

@@ -51,6 +51,8 @@ def label_of(kernel_name):
     base = short.split("<")[0].split("(")[0]
     if base == "k_sample":
         return "k_sample_tail", short
+    if base == "k_ntt4_batch":
+        return ("k_intt_batch" if "<true>" in short else "k_ntt_batch"), short
     if base == "k_encrypt":
         return ("k_encrypt_cmp" if re.search(r",\s*true>", short) else "k_encrypt"), short
     return base, short
