@@ -6,7 +6,7 @@
 // fp32 pipe (mlkem_fntt.hpp); Compress / ByteEncode / ByteDecode are integer work on a wave-private LDS byte buffer.
 // No workgroup barrier is used: the 4 waves of a workgroup are independent.
 //
-// Memory-latency structure (profiles/r01_pmc_arith.txt: 57 % of a wave's life was s_waitcnt): the wave-LDS fences are
+// Memory-latency structure (profiles/r01_pmc_sq_arith_before_prefetch.txt: 57 % of a wave's life was s_waitcnt): the wave-LDS fences are
 // compiler barriers, so a load written next to its use is issued next to its use.  Every kernel therefore issues ALL
 // of its prologue loads (PRF bytes, packed key / ciphertext polynomials, message bits) before the first NTT, and the
 // rows of the sampled matrix are double-buffered: row a+1 is requested before row a is consumed.

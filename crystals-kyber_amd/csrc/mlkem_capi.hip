@@ -126,7 +126,7 @@ int mlkem_ctx_create(mlkem_ctx** out, int device, size_t chunk_items) {
     if (hn < n) hn = n;
     if (const char* e = getenv("MLKEM_RING")) { const int r = atoi(e); c->ws.ring = (r == 128 || r == 64 || r == 32) ? r : 0; }
     // Sampler/arithmetic overlap on a helper stream is opt-in (MLKEM_OVERLAP=1): measured on MI355X it does not pay,
-    // because both kernel families are VALU-issue-bound (profiles/r01_overlap.txt); it doubles the chunk scratch.
+    // because both kernel families are VALU-issue-bound (profiles/r02_sampler_experiments.txt: +1 % step time); it doubles the chunk scratch.
     const char* ov = getenv("MLKEM_OVERLAP");
     const bool overlap = ov && atoi(ov) == 1;
     const size_t nbuf = overlap ? 2 : 1;

@@ -212,13 +212,21 @@ __device__ __forceinline__ void wave4_intt_r(float (&lo)[8], float (&hi)[8], con
     }
 }
 
+#ifndef MLKEM_RNTT_SDWA
+#define MLKEM_RNTT_SDWA 0   // 1: v_cvt_f32_u32_sdwa picks its 16-bit half (3 instead of 4 instructions per dword) -- measured 4 % SLOWER
+#endif                      //    (0.221 against 0.213 ms per 2^20 polynomials, alternating runs on one box), so the plain form stays
 // 8 coefficients (16 bytes) <-> registers; inputs are taken mod 2^12 like the reference's 12-bit `union integer.t`
 __device__ __forceinline__ void rntt_unpack(const uint4 v, float (&x)[8]) {
     const uint32_t w[4] = {v.x & 0x0FFF0FFFu, v.y & 0x0FFF0FFFu, v.z & 0x0FFF0FFFu, v.w & 0x0FFF0FFFu};
 #pragma unroll
     for (int i = 0; i < 4; i++) {
+#if defined(MLKEM_EMU) || !MLKEM_RNTT_SDWA
         x[2 * i] = (float)(w[i] & 0xFFFFu);
         x[2 * i + 1] = (float)(w[i] >> 16);
+#else   // one mask per dword, then the conversion selects its 16-bit half itself (SDWA): 3 instructions per 2 coefficients, not 4
+        asm("v_cvt_f32_u32_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0" : "=v"(x[2 * i]) : "v"(w[i]));
+        asm("v_cvt_f32_u32_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "=v"(x[2 * i + 1]) : "v"(w[i]));
+#endif
     }
 }
 __device__ __forceinline__ uint4 rntt_pack_canonical(const float (&x)[8]) {
