@@ -117,6 +117,7 @@ constexpr Tw FZ1 = tw_const(cx_centered(cx_pow17(cx_bitrev7(1))));
 constexpr Tw FZ2 = tw_const(cx_centered(cx_pow17(cx_bitrev7(2))));
 constexpr Tw FZ3 = tw_const(cx_centered(cx_pow17(cx_bitrev7(3))));
 constexpr Tw F_INV128 = tw_const(INV128 - KQ);   // 128^-1 = 3303 = -26 mod q (ml_kem.c:378-381)
+constexpr Tw F_INV128_Z1 = tw_const(cx_centered((INV128 * cx_pow17(cx_bitrev7(1))) % KQ));   // zeta_1 / 128 mod q
 
 // Cooley-Tukey (ml_kem.c:311-324): a' = a + zeta b, b' = a - zeta b ; bounds grow by 1665 per layer
 __device__ __forceinline__ void ct_bfly_f(float& a, float& b, Tw zeta) {
@@ -225,10 +226,13 @@ __device__ __forceinline__ void wave_intt_f(float (&x)[4], float* xch, const Ntt
     MLKEM_FX_WRITE(idx_LB)
     wave_lds_fence();
     MLKEM_FX_READ(idx_LA)
-    gs_bfly_c(x[0], x[1], FZ3); gs_bfly_c(x[2], x[3], FZ2);          // len 64
-    gs_bfly_c(x[0], x[2], FZ1); gs_bfly_c(x[1], x[3], FZ1);          // len 128 : <= 6660
+    gs_bfly_c(x[0], x[1], FZ3); gs_bfly_c(x[2], x[3], FZ2);          // len 64 : sums <= 3330
 #pragma unroll
-    for (int m = 0; m < 4; m++) x[m] = fmulmod_shoup(F_INV128, x[m]);  // x 128^-1 : |-26 * 6660| << 2^24
+    for (int m = 0; m < 2; m++) {                                     // len 128 with the final x 128^-1 (ml_kem.c:378-381) folded in:
+        const float sum = x[m] + x[m + 2], dif = x[m + 2] - x[m];     //   a' = 128^-1 (a + b), b' = (zeta_1 128^-1)(b - a); |sum|, |dif| <= 6660
+        x[m] = fmulmod_shoup(F_INV128, sum);
+        x[m + 2] = fmulmod_shoup(F_INV128_Z1, dif);
+    }
     wave_lds_fence();
     MLKEM_FX_WRITE(idx_LA)
     wave_lds_fence();

@@ -190,7 +190,6 @@ __device__ __forceinline__ void wave4_ntt_r(float (&lo)[8], float (&hi)[8], cons
     ct_bfly_s(hi[4], hi[6], t.z1[1][1]); ct_bfly_s(hi[5], hi[7], t.z1[1][1]);
 }
 
-constexpr Tw F_INV128_Z1 = tw_const(cx_centered((INV128 * cx_pow17(cx_bitrev7(1))) % KQ));   // zeta_1 / 128 mod q
 // Inverse NTT including the multiplication by 128^-1 (ml_kem.c:336-384).  In: 0 <= x <= 4095.  Out: |x| <= 1668.
 __device__ __forceinline__ void wave4_intt_r(float (&lo)[8], float (&hi)[8], const RnttTw& t) {
     gs_bfly_s(lo[0], lo[2], t.z1[0][0]); gs_bfly_s(lo[1], lo[3], t.z1[0][0]);   // len 2 : sums <= 8190, products <= 1668

@@ -20,6 +20,9 @@ for wl in kem768 ntt kem1024; do
     run kt_$wl --kernel-trace --stats --output-format csv -d "$OUT/kt_$wl" -o $wl -- python3 "$ROOT/bench.py" --workload $wl --no-cpu --no-also --steps $steps --warmup 2 || exit 1
     run fetch_$wl --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/fetch_$wl" -o $wl -- python3 "$ROOT/bench.py" --workload $wl --no-cpu --no-also --steps 3 --warmup 1 || exit 1
     run write_$wl --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/write_$wl" -o $wl -- python3 "$ROOT/bench.py" --workload $wl --no-cpu --no-also --steps 3 --warmup 1 || exit 1
+    # SQ view of the same command: issue utilisation (VALU instructions per SIMD-cycle), waiting, LDS use
+    run sq_$wl --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_LDS SQ_INSTS_SALU GRBM_GUI_ACTIVE \
+        --kernel-trace --output-format csv -d "$OUT/sq_$wl" -o $wl -- python3 "$ROOT/bench.py" --workload $wl --no-cpu --no-also --steps 3 --warmup 1 || exit 1
 done
 find "$OUT" -name '*.csv' | sed "s|$ROOT/||" | sort
 du -sh "$OUT"
