@@ -73,7 +73,10 @@ def dist_setup(n_gpus, rehearse=False):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    launched = world > 1 or all(k in os.environ for k in ("RANK", "WORLD_SIZE", "MASTER_PORT"))
+    if launched:
+        # also for a single rank started by torch.distributed.run: the RCCL group, barrier and max-reduce of the N > 1
+        # path then run on a one-GPU box as well (tests/test_gpu_round2.py)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         ndev = torch.cuda.device_count()   # counting devices does not initialise the GPU
@@ -85,21 +88,28 @@ def dist_setup(n_gpus, rehearse=False):
         else:
             torch.cuda.set_device(local)
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+        if os.environ.get("BENCH_TRACE_DIST"):
+            print("dist backend %s, rank %d of %d, device %d" % (dist.get_backend(), rank, world, local), file=sys.stderr)
     elif n_gpus > 1:
         raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one process per GPU)")
     return rank, world, local
 
 
+def _dist():
+    import torch.distributed as dist
+    return dist if dist.is_available() and dist.is_initialized() else None
+
+
 def barrier(world):
-    if world > 1:
-        import torch.distributed as dist
+    dist = _dist()
+    if dist is not None:
         dist.barrier()
 
 
 def max_over_ranks(x, world, device):
-    if world == 1:
+    dist = _dist()
+    if dist is None:
         return x
-    import torch.distributed as dist
     on_cpu = SHARED_GPU or dist.get_backend() == "gloo"
     t = torch.tensor([x], dtype=torch.float64, device="cpu" if on_cpu else device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -425,9 +435,8 @@ def main():
             ok = ok and ok2
             torch.cuda.empty_cache()
 
-    if world > 1:
-        import torch.distributed as dist
-        dist.destroy_process_group()
+    if _dist() is not None:
+        _dist().destroy_process_group()
     if rank != 0:
         return
     e = entry(args.workload, args, elapsed, ok, extra, world)

@@ -339,3 +339,24 @@ def test_bench_two_rank_rehearsal_prints_a_valid_line(tmp_path):
     assert j["n_gpus"] == 2 and j["correct"] is True and j["scaling"] == "weak" and j["steps"] == 2
     assert "REHEARSAL" in j["config"]["parallelism"] and j["value"] > 0 and j["unit"] == "pairs/s"
     assert abs(j["value"] - 2 * 8192 * 2 / (j["ms_per_step"] * 2e-3)) / j["value"] < 1e-6   # whole-job aggregate over both ranks
+
+
+def test_bench_rccl_group_with_one_rank(tmp_path):
+    """The RCCL leg of the N > 1 path (process group bound to the rank's device, barrier and MAX all-reduce on the device)
+    on a one-GPU box: torch.distributed.run with a single rank makes bench.py initialise the group exactly as it does for
+    one rank per GPU on the 8-GPU node."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", BENCH_TRACE_DIST="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+                        "--batch", "8192", "--no-cpu", "--no-also"], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 1 and j["correct"] is True and "REHEARSAL" not in j["config"]["parallelism"]
+    assert "dist backend nccl" in r.stderr   # the group really was RCCL
