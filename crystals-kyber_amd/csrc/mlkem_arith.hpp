@@ -19,8 +19,14 @@ namespace mlkem {
 #define MLKEM_ARITH_WAVES 4
 #endif
 constexpr int ARITH_WAVES = MLKEM_ARITH_WAVES;   // waves per workgroup (each fully independent)
-#ifndef MLKEM_ARITH_MINWAVES
-#define MLKEM_ARITH_MINWAVES 1   // __launch_bounds__ second argument of the K-PKE kernels (register budget knob)
+// __launch_bounds__ second argument of the K-PKE kernels = resident waves per SIMD the register allocator aims at.  The
+// kernels hide their LDS-exchange latency with occupancy (A/B on one box, tools/ab_bench.sh: 6 waves beat 5 by 3-4 % in
+// k_encrypt<3>; a loop-over-items form with 13 % fewer instructions but 4 waves was slower): 6 where the LDS block allows
+// it (k = 2, 3: 18-24 KB per workgroup), 5 for k = 4 (30 KB).  MLKEM_ARITH_MINWAVES overrides for experiments.
+#ifdef MLKEM_ARITH_MINWAVES
+constexpr int arith_minwaves(int) { return MLKEM_ARITH_MINWAVES; }
+#else
+constexpr int arith_minwaves(int k) { return k == 4 ? 5 : 6; }
 #endif
 
 template <int K>
@@ -157,7 +163,7 @@ __device__ __forceinline__ void emit_encode12(uint32_t* cbuf, const float (&x)[4
 //   COMPARE = true  : compare c' with c, K = (c == c') ? K' : Kbar (Decaps_internal, ml_kem.c:1206-1215)
 // ------------------------------------------------------------------------------------------------
 template <int K, int ETA1, int DU, int DV, bool COMPARE>
-__global__ void __launch_bounds__(WAVE * ARITH_WAVES, MLKEM_ARITH_MINWAVES)
+__global__ void __launch_bounds__(WAVE * ARITH_WAVES, arith_minwaves(K))
 k_encrypt(size_t n, const uint8_t* __restrict__ ek, size_t ek_stride, const uint8_t* __restrict__ msg, const uint16_t* __restrict__ A,
           const uint8_t* __restrict__ prf, uint8_t* __restrict__ c_out, const uint8_t* __restrict__ c_in, const uint8_t* __restrict__ Kp,
           const uint8_t* __restrict__ Kbar, uint8_t* __restrict__ Kout, int32_t* __restrict__ mod_status, size_t a_stride) {
@@ -166,7 +172,7 @@ k_encrypt(size_t n, const uint8_t* __restrict__ ek, size_t ek_stride, const uint
     // mod_status (optional): per-item result of the FIPS 203 encapsulation-key modulus check, 0 or -4.  The reference's
     // own check can never fail (ml_kem.c:1273-1291, F3), so its callers pass nullptr.
     __shared__ ArithLds<K> lds_all[ARITH_WAVES];
-    const int wv = (int)(threadIdx.x >> 6), l = lane_id();
+    const int wv = wave_id(), l = lane_id();
     const size_t item = (size_t)blockIdx.x * ARITH_WAVES + wv;
     if (item >= n) return;
     ArithLds<K>& L = lds_all[wv];
@@ -187,22 +193,16 @@ k_encrypt(size_t n, const uint8_t* __restrict__ ek, size_t ek_stride, const uint
 #pragma unroll
     for (int a = 0; a < K; a++) raw_e1[a] = cbd_load<2>(my_prf + (K + a) * PS);
     raw_e2 = cbd_load<2>(my_prf + (2 * K) * PS);
-    CodecRegs<12> that[K];
-#pragma unroll
-    for (int b = 0; b < K; b++) codec_fetch<12>(my_ek + 384 * b, that[b]);
     const unsigned mb = msg[item * 32 + (l >> 1)] >> (4 * (l & 1));   // the lane's 4 message bits
-    CodecRegs<DU> cu_ref[COMPARE ? K : 1];
+    CodecRegs<DU> cu_ref;   // the ciphertext row the current u row is compared with (fetched one row ahead)
     CodecRegs<DV> cv_ref;
-    if constexpr (COMPARE) {
-#pragma unroll
-        for (int a = 0; a < K; a++) codec_fetch<DU>(my_cin + a * 32 * DU, cu_ref[a]);
-        codec_fetch<DV>(my_cin + K * 32 * DU, cv_ref);
-    }
+    if constexpr (COMPARE) codec_fetch<DU>(my_cin, cu_ref);
     NttTwiddlesF tw;
     load_twiddles_f(tw);
 
     uint32_t diff = 0;
     float x[4];
+    CodecRegs<12> that[K];
     // y-hat = NTT(CBD_eta1(PRF(r, n)))  n = 0..K-1   (ml_kem.c:826-836)
 #pragma unroll
     for (int b = 0; b < K; b++) {
@@ -235,7 +235,15 @@ k_encrypt(size_t n, const uint8_t* __restrict__ ek, size_t ek_stride, const uint
         cbd_eval_f<2>(raw_e1[a], e);
 #pragma unroll
         for (int m = 0; m < 4; m++) acc[m] += e[m];
-        diff |= emit_compressed<DU, COMPARE>(L.cbuf, acc, COMPARE ? nullptr : my_c + a * 32 * DU, cu_ref[COMPARE ? a : 0]);
+        diff |= emit_compressed<DU, COMPARE>(L.cbuf, acc, COMPARE ? nullptr : my_c + a * 32 * DU, cu_ref);
+        if constexpr (COMPARE) {
+            if (a + 1 < K) codec_fetch<DU>(my_cin + (a + 1) * 32 * DU, cu_ref);
+            else codec_fetch<DV>(my_cin + K * 32 * DU, cv_ref);
+        }
+        if (a == K - 2 || K == 1) {   // t-hat is needed after the last row: fetch it one row ahead
+#pragma unroll
+            for (int b = 0; b < K; b++) codec_fetch<12>(my_ek + 384 * b, that[b]);
+        }
     }
     // v = InverseNTT(t-hat . y-hat) + e2 + Decompress_1(m)  ->  Compress_dv, ByteEncode_dv   (ml_kem.c:867-904)
     {
@@ -277,10 +285,10 @@ k_encrypt(size_t n, const uint8_t* __restrict__ ek, size_t ek_stride, const uint
 // k_decrypt — K-PKE.Decrypt (ml_kem.c:942-1023): m' = ByteEncode_1(Compress_1(v - InverseNTT(s-hat . NTT(u))))
 // ------------------------------------------------------------------------------------------------
 template <int K, int DU, int DV>
-__global__ void __launch_bounds__(WAVE * ARITH_WAVES, MLKEM_ARITH_MINWAVES)
+__global__ void __launch_bounds__(WAVE * ARITH_WAVES, arith_minwaves(K))
 k_decrypt(size_t n, const uint8_t* __restrict__ dk, size_t dk_stride, const uint8_t* __restrict__ c, uint8_t* __restrict__ m_out) {
     __shared__ ArithLds<1> lds_all[ARITH_WAVES];
-    const int wv = (int)(threadIdx.x >> 6), l = lane_id();
+    const int wv = wave_id(), l = lane_id();
     const size_t item = (size_t)blockIdx.x * ARITH_WAVES + wv;
     if (item >= n) return;
     ArithLds<1>& L = lds_all[wv];
@@ -330,11 +338,11 @@ k_decrypt(size_t n, const uint8_t* __restrict__ dk, size_t dk_stride, const uint
 // KEM_DK = true : dk rows are the ML-KEM decapsulation keys (768k+96 bytes: ŝ ‖ ek ‖ H(ek) ‖ z; this kernel fills ŝ ‖ ek)
 // KEM_DK = false: K-PKE.KeyGen on its own (ml_kem.c:651-769): dk rows are the 384k bytes of ŝ only
 template <int K, int ETA1, bool KEM_DK>
-__global__ void __launch_bounds__(WAVE * ARITH_WAVES, MLKEM_ARITH_MINWAVES)
+__global__ void __launch_bounds__(WAVE * ARITH_WAVES, arith_minwaves(K))
 k_keygen(size_t n, const uint16_t* __restrict__ A, const uint8_t* __restrict__ prf, const uint8_t* __restrict__ rho,
          uint8_t* __restrict__ ek, uint8_t* __restrict__ dk) {
     __shared__ ArithLds<K> lds_all[ARITH_WAVES];
-    const int wv = (int)(threadIdx.x >> 6), l = lane_id();
+    const int wv = wave_id(), l = lane_id();
     const size_t item = (size_t)blockIdx.x * ARITH_WAVES + wv;
     if (item >= n) return;
     ArithLds<K>& L = lds_all[wv];

@@ -177,6 +177,15 @@ __device__ __forceinline__ uint32_t& keccak_word(KeccakState& s) {
 // wave-level helpers
 // ----------------------------------------------------------------------------------------------
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+// index of the wave inside its workgroup as a wave-uniform (scalar) value: everything derived from it -- the item index,
+// the item's base pointers, the wave's LDS block -- then lives in SGPRs and its arithmetic runs on the scalar unit
+__device__ __forceinline__ int wave_id() {
+#ifdef MLKEM_EMU
+    return (int)(threadIdx.x >> 6);
+#else
+    return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+#endif
+}
 // lane id the compiler cannot merge with an earlier lane_id(): values derived from it are recomputed where they are
 // used instead of being kept in registers across a permutation
 __device__ __forceinline__ int lane_id_fresh() {
