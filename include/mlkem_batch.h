@@ -192,7 +192,8 @@ int mlkem_compress(int d, size_t n, const uint16_t* x, uint16_t* y);
 int mlkem_decompress(int d, size_t n, const uint16_t* y, uint16_t* x);
 /* All state the host-pointer calls cache is kept PER DEVICE (the HIP device current in the calling thread): threads that
  * work on different devices share nothing.  mlkem_host_release() zeroes and frees all of it (contexts, streams, pinned and
- * device staging) on every device; mlkem_stream_release() only the streaming engines. */
+ * device staging) on every device; mlkem_stream_release() only the streaming engines.  Neither may run while another
+ * thread is inside a host-pointer call (they free what that call is using). */
 void mlkem_host_release(void);
 
 /* ---- layout converters and streaming front-end --------------------------------------------------

@@ -182,3 +182,45 @@ def test_sha3_pad_suffix_host_helper(pkg):
     assert lib.mlkem_sha3_pad_bits(bits.ctypes.data, 3, 1, 168, out2.ctypes.data, out2.size) == 1
     assert out2[0] == 0b11111101 and out2[167] == 0x80
     assert lib.mlkem_sha3_pad_suffix(bits.ctypes.data, 3, sfx.ctypes.data, 9, 168, out.ctypes.data, out.size) == -101
+
+
+def test_rng_failure_sets_ml_errno_minus_2(pkg, tmp_path):
+    """ml_kem.c:458-478, :1245-1251, :1298-1304: when the random source fails, KEM_KeyGen / KEM_Encaps set ml_errno = -2
+    (the shim returns zeroed structs where the reference returns uninitialised ones).  The random draw comes before any
+    device work, so this runs without a GPU: a child process preloads an interposer whose getrandom() always fails."""
+    import subprocess
+    import sys
+    src = tmp_path / "norandom.c"
+    src.write_text("#include <errno.h>\n#include <sys/types.h>\n"
+                   "ssize_t getrandom(void* b, size_t n, unsigned f) { (void)b; (void)n; (void)f; errno = ENOSYS; return -1; }\n")
+    so = tmp_path / "libnorandom.so"
+    subprocess.run(["gcc", "-shared", "-fPIC", "-o", str(so), str(src)], check=True)
+    child = r'''
+import ctypes as C, sys
+class RawParams(C.Structure):
+    _fields_ = [(n, C.c_uint) for n in ("k", "n1", "n2", "du", "dv")]
+class RawPKE(C.Structure):
+    _fields_ = [("ek", C.POINTER(C.c_uint)), ("dk", C.POINTER(C.c_uint)), ("ek_len", C.c_uint), ("dk_len", C.c_uint)]
+class RawKEM(C.Structure):
+    _fields_ = [("K", C.c_uint * 32), ("c", C.POINTER(C.c_uint)), ("c_len", C.c_uint)]
+shim = C.CDLL(sys.argv[1])
+shim.init.restype = RawParams
+errno = C.c_int.in_dll(shim, "ml_errno")
+for pset, ek_len in ((512, 800), (768, 1184), (1024, 1568)):
+    p = shim.init(pset)
+    shim.KEM_KeyGen.restype = RawPKE
+    shim.KEM_KeyGen.argtypes = [C.POINTER(RawParams)]
+    errno.value = 0
+    r = shim.KEM_KeyGen(C.byref(p))
+    assert errno.value == -2 and not r.ek and not r.dk and r.ek_len == 0 and r.dk_len == 0, (pset, errno.value)
+    shim.KEM_Encaps.restype = RawKEM
+    shim.KEM_Encaps.argtypes = [C.POINTER(RawParams), C.POINTER(C.c_uint), C.c_uint]
+    errno.value = 0
+    k = shim.KEM_Encaps(C.byref(p), (C.c_uint * ek_len)(), ek_len)
+    assert errno.value == -2 and not k.c and k.c_len == 0 and not any(k.K), (pset, errno.value)
+print("rng-failure OK")
+'''
+    env = dict(os.environ, LD_PRELOAD=str(so))
+    r = subprocess.run([sys.executable, "-c", child, pkg.SHIM_PATH], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0 and "rng-failure OK" in r.stdout, (r.stdout[-1000:], r.stderr[-2000:])
+    assert "Random bit generation failed" in r.stderr   # the reference's message (ERR_MSG, ml_kem.c:11-13)
