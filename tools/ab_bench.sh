@@ -7,7 +7,7 @@ mkdir -p gpurun_out/ab
 for r in $(seq 1 $R); do
   for lib in "$@"; do
     tag=$(basename $lib .so)
-    MLKEM_LIB_PATH=$PWD/$lib python bench.py --workload $WL --no-cpu --no-also --steps ${STEPS:-20} > gpurun_out/ab/$tag$r.json 2> gpurun_out/ab/$tag$r.err || { tail -5 gpurun_out/ab/$tag$r.err; exit 1; }
+    MLKEM_LIB_PATH=$PWD/$lib python bench.py --workload $WL --no-cpu --no-also --steps ${STEPS:-20} > gpurun_out/ab/$tag$r.json 2> gpurun_out/ab/$tag$r.err || true
     python - $tag $r <<'P'
 import json,sys
 d=json.load(open('gpurun_out/ab/%s%s.json'%(sys.argv[1],sys.argv[2])))
