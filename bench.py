@@ -18,7 +18,9 @@ measured in the same process right after the headline, each with value / ms_per_
 
 Extra objects on the line:
   roofline      whole-pass algorithmic bytes (5856 B per pair) / pass time vs the 8 TB/s HBM peak, the
-                dominant kernel by HIP-event time, and the integer-VALU view that actually binds this path
+                dominant kernel by HIP-event time, the integer-VALU view that actually binds this path, and
+                `clock_power`: shader clock and socket power sampled with rocm-smi while the same steps keep running
+                (the path runs into the socket power limit; nominal clock 2400 MHz)
   cpu_baseline  the real reference (oracle/_ref, `kind: reference`) or the oracle restatement (`kind: port`) timed
                 on this box's host cores on a bounded sample of the same items, outputs cross-checked against the GPU
 """
@@ -135,6 +137,46 @@ def host_cores():
     return n
 
 
+def clock_power_probe(step, device, seconds=1.6):
+    """Shader clock and socket power while the workload runs (untimed, after the timed region): the hot path runs into
+    the socket power limit, and the line should carry the evidence.  Best effort: rocm-smi polled from a helper thread
+    while this thread keeps the GPU busy; returns None when rocm-smi is not usable."""
+    import re
+    import shutil
+    import subprocess
+    import threading
+    smi = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
+    if not os.path.exists(smi):
+        return None
+    samples, stop = [], threading.Event()
+
+    def poll():
+        time.sleep(0.3)   # let the clock settle under load first
+        while not stop.is_set() and len(samples) < 4:
+            try:
+                out = subprocess.run([smi, "-d", str(device.index), "--showclocks", "--showpower"], capture_output=True, text=True, timeout=5).stdout
+            except (OSError, subprocess.SubprocessError):
+                break
+            c = re.search(r"sclk clock level: \S+ \((\d+)Mhz\)", out)
+            p = re.search(r"Power \(W\): ([\d.]+)", out)
+            if c and p:
+                samples.append((int(c.group(1)), float(p.group(1))))
+        stop.set()
+
+    th = threading.Thread(target=poll, daemon=True)
+    th.start()
+    t_end = time.perf_counter() + seconds
+    while not stop.is_set() and time.perf_counter() < t_end:
+        step()
+        torch.cuda.synchronize(device)
+    stop.set()
+    th.join(timeout=6)
+    if not samples:
+        return None
+    return {"sclk_mhz": [s[0] for s in samples], "socket_w": [s[1] for s in samples],
+            "how": "rocm-smi polled while the same steps keep running after the timed region (nominal shader clock 2400 MHz)"}
+
+
 def cpu_baseline(pset, ek, dk, m, c_gpu, K_gpu, want_seconds=20.0):
     """Time the reference (or the port) on the host cores over a bounded sample of the SAME items."""
     from concurrent.futures import ThreadPoolExecutor
@@ -242,6 +284,8 @@ def run_kem(args, pset, rank, world, device):
                 for k, v in kt.rows.items()}
         extra["kernels"] = rows
         extra["chunk_items"] = args.chunk or int(os.environ.get("MLKEM_CHUNK_ITEMS", 1 << 18))
+        if world == 1:
+            extra["clock_power"] = clock_power_probe(step, device)
         if world == 1 and not args.no_cpu:
             if shared:   # the reference has no shared-key path: every pair pays for the full key handling
                 extra["cpu_baseline"] = cpu_baseline(pset, ek[:1].expand(n, -1), dk[:1].expand(n, -1), m, c, K)
@@ -285,6 +329,8 @@ def run_ntt(args, rank, world, device):
             torch.cuda.synchronize(device)
         extra["kernels"] = {k: {"ms_total": v[0] / TIMING_PASSES, "launches": v[1] // TIMING_PASSES, "ms_avg": v[0] / max(v[1], 1)}
                             for k, v in kt.rows.items()}
+        if world == 1:
+            extra["clock_power"] = clock_power_probe(step, device)
         if world == 1 and not args.no_cpu:
             from oracle import loader
             orc = loader.Oracle()
@@ -388,6 +434,8 @@ def entry(workload, args, elapsed, ok, extra, world):
                                "frac_keccak_only": value / world * keccak_ops / VALU_PEAK_LANE_OPS,
                                "note": "the pass runs into the socket power limit (rocm-smi: ~1340 W, shader clock ~2.07 GHz instead of "
                                        "2.4 GHz; DESIGN.md section 5, profiles/r01_clock_power_watch.txt, profiles/r01_power_ubench.txt)"}
+    if extra.get("clock_power"):
+        roofline["clock_power"] = extra["clock_power"]
     return {"value": value, "ms_per_step": ms_step, "correct": ok, "roofline": roofline, "kernels": kernels}
 
 
