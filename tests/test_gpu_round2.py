@@ -360,3 +360,56 @@ def test_bench_rccl_group_with_one_rank(tmp_path):
     j = json.loads(lines[0])
     assert j["n_gpus"] == 1 and j["correct"] is True and "REHEARSAL" not in j["config"]["parallelism"]
     assert "dist backend nccl" in r.stderr   # the group really was RCCL
+
+
+def test_batch_whose_buffers_cross_4GiB(pkg, torch, oracle):
+    """A 288 GB device holds batches whose buffers are larger than 4 GiB (ML-KEM-1024 at 3 x 2^20 + 5 items: dk 10 GB, ek and c
+    4.9 GB each), so every byte offset must be 64-bit: K_encaps == K_decaps for all items, tampered ciphertexts rejected, and
+    the items that straddle each buffer's 4 GiB line (and the ragged tail) are compared with the oracle."""
+    pset, n = 1024, 3 * (1 << 20) + 5
+    ekl, dkl, cl = SIZES[pset]
+    free, _ = torch.cuda.mem_get_info()
+    if free < 40 << 30:
+        pytest.skip("needs 40 GB of free HBM")
+    e = pkg.MLKEM(pset, device=0)
+    g = torch.Generator(device="cuda").manual_seed(4096)
+    d, z, m = (torch.randint(0, 256, (n, 32), generator=g, device="cuda", dtype=torch.uint8) for _ in range(3))
+    ek, dk = e.keygen(d, z)
+    c, K = e.encaps(ek, m)
+    assert dk.numel() > 1 << 32 and ek.numel() > 1 << 32 and c.numel() > 1 << 32
+    ct = c.clone()
+    idx = torch.arange(0, n, 4096, device="cuda")
+    ct[idx, (idx * 11) % cl] ^= 4
+    Kd, st = e.decaps(dk, ct)
+    same = (Kd == K).all(dim=1)
+    assert int(st.abs().max()) == 0 and not bool(same[idx].any()) and int(same.sum()) == n - idx.numel()
+    cross = sorted({(1 << 32) // L + k for L in (ekl, dkl, cl) for k in (-1, 0, 1)} | {0, n - 2, n - 1})
+    sub = torch.tensor(cross, device="cuda")
+    ek_o, dk_o = oracle.keygen(pset, host(d[sub]), host(z[sub]))
+    c_o, K_o = oracle.encaps(pset, ek_o, host(m[sub]))
+    assert (host(ek[sub]) == ek_o).all() and (host(dk[sub]) == dk_o).all()
+    assert (host(c[sub]) == c_o).all() and (host(K[sub]) == K_o).all()
+    Kd_o, st_o = oracle.decaps(pset, dk_o, host(ct[sub]))
+    assert (host(Kd[sub]) == Kd_o).all() and (st_o == 0).all()
+    del ek, dk, c, ct, K, Kd
+    e.close()
+    torch.cuda.empty_cache()
+
+
+def test_ntt_buffers_beyond_4GiB(pkg, eng, torch, oracle):
+    """2^23 + 3 polynomials = 4.3 GB per buffer: round trip over the whole batch, oracle on the polynomials around the 4 GiB
+    line and on the ragged last quad."""
+    n = (1 << 23) + 3
+    free, _ = torch.cuda.mem_get_info()
+    if free < 20 << 30:
+        pytest.skip("needs 20 GB of free HBM")
+    g = torch.Generator(device="cuda").manual_seed(23)
+    f = torch.randint(0, 3329, (n, 256), generator=g, device="cuda", dtype=torch.int16)
+    fh = eng.ntt(f)
+    back = eng.intt(fh)
+    assert torch.equal(back, f)
+    line = (1 << 32) // 512
+    sub = torch.tensor([0, line - 2, line - 1, line, line + 1, n - 4, n - 3, n - 2, n - 1], device="cuda")
+    assert (host(fh[sub]).view(np.uint16) == oracle.ntt(host(f[sub]).view(np.uint16))).all()
+    del f, fh, back
+    torch.cuda.empty_cache()
