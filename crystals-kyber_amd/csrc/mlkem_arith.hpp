@@ -50,7 +50,7 @@ __device__ __forceinline__ uint2 load_poly_raw(const uint16_t* p) {
 #if MLKEM_EXP_A384   // TIMING EXPERIMENT ONLY (wrong results): the wave touches 384 of the polynomial's 512 bytes
     return *reinterpret_cast<const uint2*>(p + 3 * lane_id());
 #else
-    return *reinterpret_cast<const uint2*>(p + 4 * lane_id());
+    return stream_load8(p + 4 * lane_id());
 #endif
 }
 __device__ __forceinline__ void poly_raw_to_f(const uint2 v, float (&x)[4]) {
@@ -99,7 +99,7 @@ __device__ __forceinline__ void codec_fetch(const uint8_t* g, CodecRegs<D>& r) {
     const int l = lane_id();
     const uint32_t* gw = reinterpret_cast<const uint32_t*>(g);
 #pragma unroll
-    for (int i = 0; i < CodecRegs<D>::NW; i++) r.w[i] = (l + 64 * i < 8 * D) ? gw[l + 64 * i] : 0u;
+    for (int i = 0; i < CodecRegs<D>::NW; i++) r.w[i] = (l + 64 * i < 8 * D) ? stream_load4(gw + l + 64 * i) : 0u;
 }
 // ByteDecode_D (+ optional Decompress_D) (ml_kem.c:153-177, :104-119) of pre-fetched bytes -> 4 floats per lane
 template <int D, bool DECOMPRESS>

@@ -177,6 +177,42 @@ __device__ __forceinline__ uint32_t& keccak_word(KeccakState& s) {
 // wave-level helpers
 // ----------------------------------------------------------------------------------------------
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+// Single-use streams of the K-PKE kernels: the sampled matrix A-hat (written once by the sampler, read once, 1.2-2.5 GB per
+// chunk: far beyond the 4 MB L2 of an XCD) and the packed key / ciphertext rows.  MLKEM_A_NT is a bit set: 1 = A-hat loads,
+// 4 = packed-row loads carry the non-temporal hint (A/B on one box, tools/ab_bench.sh: -0.4..-0.7 % step time, at the edge of
+// the noise); 2 = the sampler's A-hat stores as well: those are 32-byte pieces of a lane's own row, and as non-temporal
+// stores they are no longer merged in L2 - k_sample_main 1.12 -> 3.73 ms.  Default 5.
+#ifndef MLKEM_A_NT
+#define MLKEM_A_NT 5
+#endif
+__device__ __forceinline__ void stream_store16(void* p, const uint4 v) {
+#if (MLKEM_A_NT & 2) && !defined(MLKEM_EMU)
+    typedef unsigned v4 __attribute__((ext_vector_type(4)));
+    v4 t;
+    t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
+    __builtin_nontemporal_store(t, reinterpret_cast<v4*>(p));
+#else
+    *reinterpret_cast<uint4*>(p) = v;
+#endif
+}
+__device__ __forceinline__ uint32_t stream_load4(const uint32_t* p) {
+#if (MLKEM_A_NT & 4) && !defined(MLKEM_EMU)
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
+__device__ __forceinline__ uint2 stream_load8(const void* p) {
+#if (MLKEM_A_NT & 1) && !defined(MLKEM_EMU)
+    typedef unsigned v2 __attribute__((ext_vector_type(2)));
+    const v2 t = __builtin_nontemporal_load(reinterpret_cast<const v2*>(p));
+    uint2 r;
+    r.x = t.x; r.y = t.y;
+    return r;
+#else
+    return *reinterpret_cast<const uint2*>(p);
+#endif
+}
 // index of the wave inside its workgroup as a wave-uniform (scalar) value: everything derived from it -- the item index,
 // the item's base pointers, the wave's LDS block -- then lives in SGPRs and its arithmetic runs on the scalar unit
 __device__ __forceinline__ int wave_id() {

@@ -190,8 +190,8 @@ __device__ __forceinline__ void lin_flush(char* buf, uint32_t pos0, uint32_t& po
     for (uint32_t i = 0; i < 4; i++)
         if (i < n32 && valid) {
             const uint4 a = *reinterpret_cast<const uint4*>(buf + 32u * i), b = *reinterpret_cast<const uint4*>(buf + 32u * i + 16u);
-            *reinterpret_cast<uint4*>(dst_poly + flushed + 32u * i) = a;
-            *reinterpret_cast<uint4*>(dst_poly + flushed + 32u * i + 16u) = b;
+            stream_store16(dst_poly + flushed + 32u * i, a);
+            stream_store16(dst_poly + flushed + 32u * i + 16u, b);
         }
     if (n32) {   // remainder (< 32 bytes; < 16 when four pieces left, so that the row's 144 bytes are never exceeded)
         const uint4 a = *reinterpret_cast<const uint4*>(buf + 32u * n32);
