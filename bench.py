@@ -137,44 +137,47 @@ def host_cores():
     return n
 
 
-def clock_power_probe(step, device, seconds=1.6):
+def clock_power_probe(step, device, seconds=1.2):
     """Shader clock and socket power while the workload runs (untimed, after the timed region): the hot path runs into
-    the socket power limit, and the line should carry the evidence.  Best effort: rocm-smi polled from a helper thread
-    while this thread keeps the GPU busy; returns None when rocm-smi is not usable."""
-    import re
-    import shutil
-    import subprocess
+    the socket power limit, and the line should carry the evidence.  Read from the amdgpu hwmon files of the device
+    (freq1_input = sclk in Hz, power1_input = socket power in uW) by a helper thread while this thread keeps the GPU
+    busy: plain file reads, no child process.  Returns None where sysfs does not offer them."""
+    import glob
     import threading
-    smi = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
-    if not os.path.exists(smi):
+    try:
+        p = torch.cuda.get_device_properties(device)
+        hw = glob.glob("/sys/bus/pci/devices/%04x:%02x:%02x.0/hwmon/hwmon*" % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id))
+        f_clk, f_pw, f_cap = (os.path.join(hw[0], n) for n in ("freq1_input", "power1_input", "power1_cap"))
+        cap_w = int(open(f_cap).read()) / 1e6
+        int(open(f_clk).read()), int(open(f_pw).read())
+    except (OSError, ValueError, IndexError, AttributeError):
         return None
     samples, stop = [], threading.Event()
 
     def poll():
         time.sleep(0.3)   # let the clock settle under load first
-        while not stop.is_set() and len(samples) < 4:
+        while not stop.is_set():
             try:
-                out = subprocess.run([smi, "-d", str(device.index), "--showclocks", "--showpower"], capture_output=True, text=True, timeout=5).stdout
-            except (OSError, subprocess.SubprocessError):
+                samples.append((int(open(f_clk).read()) // 1000000, int(open(f_pw).read()) / 1e6))
+            except (OSError, ValueError):
                 break
-            c = re.search(r"sclk clock level: \S+ \((\d+)Mhz\)", out)
-            p = re.search(r"Power \(W\): ([\d.]+)", out)
-            if c and p:
-                samples.append((int(c.group(1)), float(p.group(1))))
-        stop.set()
+            time.sleep(0.1)
 
     th = threading.Thread(target=poll, daemon=True)
     th.start()
     t_end = time.perf_counter() + seconds
-    while not stop.is_set() and time.perf_counter() < t_end:
+    while time.perf_counter() < t_end:
         step()
         torch.cuda.synchronize(device)
     stop.set()
-    th.join(timeout=6)
+    th.join(timeout=2)
     if not samples:
         return None
-    return {"sclk_mhz": [s[0] for s in samples], "socket_w": [s[1] for s in samples],
-            "how": "rocm-smi polled while the same steps keep running after the timed region (nominal shader clock 2400 MHz)"}
+    clk, pw = sorted(s[0] for s in samples), sorted(s[1] for s in samples)
+    return {"sclk_mhz": {"min": clk[0], "median": clk[len(clk) // 2], "max": clk[-1]},
+            "socket_w": {"min": pw[0], "median": pw[len(pw) // 2], "max": pw[-1]}, "samples": len(samples),
+            "power_cap_w": cap_w, "sclk_nominal_mhz": 2400,
+            "how": "amdgpu hwmon (freq1_input, power1_input) read every 0.1 s while the same steps keep running after the timed region"}
 
 
 def cpu_baseline(pset, ek, dk, m, c_gpu, K_gpu, want_seconds=20.0):
