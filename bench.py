@@ -350,13 +350,18 @@ def run_ntt(args, rank, world, device):
 
 
 def source_id():
-    """sha256 over the kernel / C-ABI sources: ties a committed PMC traffic file to the build it was measured on (there is
-    no .git on the GPU box, so the commit hash itself cannot be checked there)."""
+    """sha256 over the CODE of the kernel / C-ABI sources (comments and white space stripped): ties a committed PMC traffic
+    file to the build it was measured on (there is no .git on the GPU box, so the commit hash itself cannot be checked
+    there); a comment edit does not invalidate a measurement."""
+    import re
     h = hashlib.sha256()
     csrc = os.path.join(ROOT, "crystals-kyber_amd", "csrc")
     for f in sorted(x for x in os.listdir(csrc) if x.endswith((".hpp", ".hip", ".c"))):   # headers under include/ only declare
-        with open(os.path.join(csrc, f), "rb") as fh:
-            h.update(f.encode() + b"\0" + fh.read())
+        with open(os.path.join(csrc, f), "r", encoding="utf-8", errors="replace") as fh:
+            text = fh.read()
+        text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)      # block comments
+        text = re.sub(r"//[^\n]*", " ", text)                    # line comments (the sources hold no '//' inside string literals)
+        h.update(f.encode() + b"\0" + " ".join(text.split()).encode())
     return h.hexdigest()[:16]
 
 

@@ -183,7 +183,8 @@ k_encrypt(size_t n, const uint8_t* __restrict__ ek, size_t ek_stride, const uint
     uint8_t* my_c = COMPARE ? nullptr : c_out + item * CLEN;
     const uint8_t* my_cin = COMPARE ? c_in + item * CLEN : nullptr;
 
-    // ---- prologue: every load whose address is known now ----
+    // ---- prologue: the loads the first phases need (PRF bytes, row 0 of A^T, message bits); the packed t-hat row and the
+    //      reference ciphertext rows follow one matrix row ahead of their use (fewer live registers: 6 waves per SIMD) ----
     uint32_t raw_y[K], raw_e1[K], raw_e2;
 #pragma unroll
     for (int b = 0; b < K; b++) raw_y[b] = cbd_load<ETA1>(my_prf + b * PS);
