@@ -282,55 +282,7 @@ k_encrypt(size_t n, const uint8_t* __restrict__ ek, size_t ek_stride, const uint
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// k_decrypt — K-PKE.Decrypt (ml_kem.c:942-1023): m' = ByteEncode_1(Compress_1(v - InverseNTT(s-hat . NTT(u))))
-// ------------------------------------------------------------------------------------------------
-template <int K, int DU, int DV>
-__global__ void __launch_bounds__(WAVE * ARITH_WAVES, arith_minwaves(K))
-k_decrypt(size_t n, const uint8_t* __restrict__ dk, size_t dk_stride, const uint8_t* __restrict__ c, uint8_t* __restrict__ m_out) {
-    __shared__ ArithLds<1> lds_all[ARITH_WAVES];
-    const int wv = wave_id(), l = lane_id();
-    const size_t item = (size_t)blockIdx.x * ARITH_WAVES + wv;
-    if (item >= n) return;
-    ArithLds<1>& L = lds_all[wv];
-    constexpr unsigned CLEN = 32 * (DU * K + DV);
-    const uint8_t* my_c = c + item * CLEN;
-    const uint8_t* my_dk = dk + item * dk_stride;
-    // prologue loads: u (ml_kem.c:978-987), s-hat (:996-998), v (:990-993)
-    CodecRegs<DU> cu[K];
-    CodecRegs<12> shat[K];
-    CodecRegs<DV> cv;
-#pragma unroll
-    for (int b = 0; b < K; b++) codec_fetch<DU>(my_c + b * 32 * DU, cu[b]);
-#pragma unroll
-    for (int b = 0; b < K; b++) codec_fetch<12>(my_dk + 384 * b, shat[b]);
-    codec_fetch<DV>(my_c + K * 32 * DU, cv);
-    NttTwiddlesF tw;
-    load_twiddles_f(tw);
-    float acc[4] = {0.f, 0.f, 0.f, 0.f}, x[4];
-#pragma unroll
-    for (int b = 0; b < K; b++) {
-        decode_regs<DU, true>(L.cbuf, cu[b], x);
-        wave_ntt_f(x, L.xch, tw);
-#pragma unroll
-        for (int m = 0; m < 4; m++) x[m] = fred(x[m]);
-        stash_vhat_f(L.vhat[0], L.vgam[0], x, tw);
-        wave_lds_fence();
-        float sv[4];
-        decode_regs<12, false>(L.cbuf, shat[b], sv);
-        basemul_acc_f(acc, sv, L.vhat[0], L.vgam[0]);
-        wave_lds_fence();
-    }
-    wave_intt_f(acc, L.xch, tw);
-    float v[4];
-    decode_regs<DV, true>(L.cbuf, cv, v);
-    unsigned bits = 0;
-#pragma unroll
-    for (int m = 0; m < 4; m++) bits |= compress_f<1>(v[m] - acc[m]) << m;   // ml_kem.c:1003-1011
-    // ByteEncode_1: lane l owns nibble l of the 32-byte message
-    const unsigned other = (unsigned)__shfl_xor((int)bits, 1);
-    if ((l & 1) == 0) m_out[item * 32 + (l >> 1)] = (uint8_t)(bits | (other << 4));
-}
+// K-PKE.Decrypt (ml_kem.c:942-1023) lives in mlkem_kpke4.hpp: four items per wave, all in registers.
 
 // ------------------------------------------------------------------------------------------------
 // k_keygen — K-PKE.KeyGen after G and sampling (ml_kem.c:696-756) + the plain copies of KeyGen_internal

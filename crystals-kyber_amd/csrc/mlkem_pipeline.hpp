@@ -15,6 +15,7 @@
 #include "mlkem_sampler.hpp"
 #include "mlkem_arith.hpp"
 #include "mlkem_rntt.hpp"
+#include "mlkem_kpke4.hpp"
 #include <stdlib.h>
 #ifndef MLKEM_EMU
 #include <vector>
@@ -286,6 +287,12 @@ inline void encaps_run(stream_t st, const ParamSet& p, size_t n, const uint8_t* 
 // ---- KEM_Decaps / Decaps_internal (ml_kem.c:1310-1359, :1136-1225) -------------------------------
 // hash_check = true reproduces the public KEM_Decaps: status[i] = -5 when H(dk.ek) != dk.h (K[i] is then
 // still the Decaps_internal result; the host shim discards it like the reference does).
+template <int K, int DU, int DV>
+inline void decrypt_launch(stream_t st, size_t n, const uint8_t* dk, size_t dk_stride, const uint8_t* c, uint8_t* m) {
+    // four items per wave (mlkem_kpke4.hpp)
+    launch("k_decrypt", k_decrypt4<K, DU, DV>, ceil_div(ceil_div(n, 4), KPKE4_WAVES), 64 * KPKE4_WAVES, st, n, dk, dk_stride, c, m);
+}
+
 template <int K, int ETA1, int DU, int DV>
 inline void decaps_run(stream_t st, const ParamSet& p, size_t n, const uint8_t* dk, const uint8_t* c, uint8_t* Kout,
                        int32_t* status, bool hash_check, const Workspace& ws) {
@@ -294,7 +301,7 @@ inline void decaps_run(stream_t st, const ParamSet& p, size_t n, const uint8_t* 
         const size_t hn = min_sz(ws.hcap, n - h0);
         const uint8_t* dkh = dk + h0 * p.dk_len;
         const uint8_t* ch = c + h0 * p.c_len;
-        launch("k_decrypt", k_decrypt<K, DU, DV>, ceil_div(hn, ARITH_WAVES), WAVE * ARITH_WAVES, st, hn, dkh, (size_t)p.dk_len, ch, ws.m);
+        decrypt_launch<K, DU, DV>(st, hn, dkh, (size_t)p.dk_len, ch, ws.m);
         int32_t* sth = (hash_check && status) ? status + h0 : (int32_t*)nullptr;
         const size_t hgrid = ceil_div(hn, WAVE);
         if (hash_check && !ws.fips)
@@ -357,7 +364,7 @@ inline void decaps_shared_run(stream_t st, const ParamSet& p, size_t n, const ui
     for (size_t h0 = 0; h0 < n; h0 += ws.hcap) {
         const size_t hn = min_sz(ws.hcap, n - h0);
         const uint8_t* ch = c + h0 * p.c_len;
-        launch("k_decrypt", k_decrypt<K, DU, DV>, ceil_div(hn, ARITH_WAVES), WAVE * ARITH_WAVES, st, hn, dk, (size_t)0, ch, ws.m);
+        decrypt_launch<K, DU, DV>(st, hn, dk, (size_t)0, ch, ws.m);
         const size_t hgrid = ceil_div(hn, WAVE);
         if (!ws.fips)
             launch("k_hash_decaps", k_hash_decaps<K, CLEN, false, 168>, hgrid, WAVE, st, hn, dk, ch, (const uint8_t*)ws.m, ws.Kp, ws.r, ws.Kbar, (int32_t*)nullptr, (size_t)0);
@@ -436,12 +443,11 @@ inline int pke_encrypt_dispatch(stream_t st, int set, size_t n, const uint8_t* e
 inline int pke_decrypt_dispatch(stream_t st, int set, size_t n, const uint8_t* dk_pke, const uint8_t* c, uint8_t* m) {
     ParamSet p;
     if (!param_set(set, p)) return -1;
-    const size_t grid = ceil_div(n, ARITH_WAVES);
     if (n == 0) return 0;
     switch (set) {
-    case 512: launch("k_decrypt", k_decrypt<2, 10, 4>, grid, WAVE * ARITH_WAVES, st, n, dk_pke, (size_t)(384 * 2), c, m); break;
-    case 768: launch("k_decrypt", k_decrypt<3, 10, 4>, grid, WAVE * ARITH_WAVES, st, n, dk_pke, (size_t)(384 * 3), c, m); break;
-    default: launch("k_decrypt", k_decrypt<4, 11, 5>, grid, WAVE * ARITH_WAVES, st, n, dk_pke, (size_t)(384 * 4), c, m); break;
+    case 512: decrypt_launch<2, 10, 4>(st, n, dk_pke, (size_t)(384 * 2), c, m); break;
+    case 768: decrypt_launch<3, 10, 4>(st, n, dk_pke, (size_t)(384 * 3), c, m); break;
+    default: decrypt_launch<4, 11, 5>(st, n, dk_pke, (size_t)(384 * 4), c, m); break;
     }
     return 0;
 }

@@ -202,6 +202,24 @@ def test_emu_k_pke_alone(emu, oracle, pset):
 
 
 @pytest.mark.parametrize("pset", (512, 768, 1024))
+def test_emu_decrypt_four_items_per_wave_every_quad_shape(emu, oracle, pset):
+    """mlkem_kpke4.hpp: K-PKE.Decrypt with four items per wave.  Every batch size mod 4 (rows beyond n redo the last item and
+    store nothing), several quads per workgroup, random ciphertext BYTES (not encryptions: every 10/11/4/5-bit field value and
+    every position of the unaligned pieces shows up) and raw 12-bit key coefficients >= q (F3), against the oracle."""
+    ekl, dkl, cl = SIZES[pset]
+    k = {512: 2, 768: 3, 1024: 4}[pset]
+    rng = np.random.default_rng(pset)
+    for n in (1, 2, 3, 4, 5, 18):
+        c = rng.integers(0, 256, (n, cl)).astype(np.uint8)
+        dkp = rng.integers(0, 256, (n, 384 * k)).astype(np.uint8)   # 12-bit fields up to 4095
+        m = np.full((n + 1, 32), 0xA5, np.uint8)                     # one guard row behind the batch
+        assert emu.emu_pke_decrypt(pset, C.c_size_t(n), p8(dkp), p8(c), p8(m)) == 0
+        for i in range(n):
+            assert (m[i] == oracle.pke_decrypt(pset, dkp[i], c[i])).all(), (n, i)
+        assert (m[n] == 0xA5).all()
+
+
+@pytest.mark.parametrize("pset", (512, 768, 1024))
 def test_emu_full_wave_hash_kernels_take_the_dma_staging(emu, oracle, pset):
     """64 + 3 items: the first wave of k_hash_encaps / k_hash_decaps / k_hash_keygen_fin is complete, so its sponges are
     fed by the LDS-DMA staging (one- and two-segment messages, partial last column at ML-KEM-512: 800 = 5*136 + 120);

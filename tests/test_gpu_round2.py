@@ -413,3 +413,22 @@ def test_ntt_buffers_beyond_4GiB(pkg, eng, torch, oracle):
     assert (host(fh[sub]).view(np.uint16) == oracle.ntt(host(f[sub]).view(np.uint16))).all()
     del f, fh, back
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("pset", (512, 768, 1024))
+def test_decrypt_four_items_per_wave_random_bytes(pkg, torch, oracle, pset):
+    """mlkem_kpke4.hpp on the device (the DPP butterflies only exist there): K-PKE.Decrypt of random ciphertext BYTES under
+    random key bytes (raw 12-bit coefficients up to 4095, F3) — every field value and piece alignment, every batch size
+    mod 4 — against the oracle."""
+    ekl, dkl, cl = SIZES[pset]
+    k = {512: 2, 768: 3, 1024: 4}[pset]
+    e = pkg.MLKEM(pset, device=0, chunk_items=256)
+    rng = np.random.default_rng(pset + 4)
+    for n in (1, 2, 3, 4, 5, 1003):
+        c = rng.integers(0, 256, (n, cl)).astype(np.uint8)
+        dkp = rng.integers(0, 256, (n, 384 * k)).astype(np.uint8)
+        m = host(e.PKE_Decrypt(dev(torch, dkp), dev(torch, c)))
+        idx = range(n) if n < 10 else list(range(0, n, 37)) + [n - 3, n - 2, n - 1]
+        for i in idx:
+            assert (m[i] == oracle.pke_decrypt(pset, dkp[i], c[i])).all(), (n, i)
+    e.close()
