@@ -2,7 +2,7 @@
 """bench.py — BASELINE.json's headline metric on MI355X:
 ML-KEM-768 encaps+decaps pairs per second at batch 2^20 (BASELINE configs[2]), inputs resident in HBM.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload kem768|kem1024|kem512|ntt] [--rehearse]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload kem768|kem1024|kem512|ntt] [--rehearse] [--inproc]
 
 One "step" = one pass of the hot path over one batch: Encaps_internal over 2^20 (ek, m) followed by KEM_Decaps
 (hash check included, as the reference's public API does) over the 2^20 (dk, c) it produced.  Keys come from the
@@ -13,6 +13,12 @@ over ranks is used.  Rank 0 prints ONE JSON line.  When the node has fewer GPUs 
 ranks share the visible GPU(s) and the barrier runs over gloo instead of RCCL: a rehearsal of the N-rank path on a
 one-GPU box (the line says so in config.parallelism; its value is not a scaling result).
 
+N > 1 lines carry `per_gpu`: one entry per rank (device, its own rate and ms/step from its own clock between the opening
+barrier and its own synchronize, shader clock and socket power sampled on that rank while all ranks keep running) next to
+the aggregate; `correct` is the AND over all ranks and every rank exits non-zero when it is false.
+--inproc: the same workload in ONE process through mlkem_{encaps,decaps}_multi_dev, one member per visible device (members
+repeat devices when there are fewer devices than --gpus: a rehearsal, labelled as such) -- the in-process form of the shard.
+
 At N = 1 the line also carries `also`: BASELINE configs[1] (NTT-only) and configs[3] (ML-KEM-1024 KeyGen+Encaps+Decaps)
 measured in the same process right after the headline, each with value / ms_per_step / correct / roofline.
 
@@ -21,8 +27,10 @@ Extra objects on the line:
                 dominant kernel by HIP-event time, the integer-VALU view that actually binds this path, and
                 `clock_power`: shader clock and socket power sampled with rocm-smi while the same steps keep running
                 (the path runs into the socket power limit; nominal clock 2400 MHz)
-  cpu_baseline  the real reference (oracle/_ref, `kind: reference`) or the oracle restatement (`kind: port`) timed
-                on this box's host cores on a bounded sample of the same items, outputs cross-checked against the GPU
+  cpu_baseline  BASELINE.md section 3's three legs, each timed on this box's host cores on a bounded sample of the same items
+                and cross-checked against the GPU bytes: `legs.reference_O2` (ml_kem.c + sha3.c, gcc -O2), `legs.reference_O0`
+                (the reference makefile's own flags, -Wall -g) and `legs.port` (the multi-threaded restatement
+                oracle/mlkem_oracle.c); the top-level fields repeat the -O2 reference (the port when oracle/_ref is absent)
 """
 import argparse
 import hashlib
@@ -118,6 +126,27 @@ def max_over_ranks(x, world, device):
     return float(t.item())
 
 
+def all_ranks_ok(ok, device):
+    """AND of the per-rank correctness gates (MIN of int(ok)): a wrong byte on ANY rank fails the whole line."""
+    dist = _dist()
+    if dist is None:
+        return bool(ok)
+    on_cpu = SHARED_GPU or dist.get_backend() == "gloo"
+    t = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cpu" if on_cpu else device)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(int(t.item()))
+
+
+def gather_per_gpu(entry):
+    """One dict per rank, in rank order (control plane, outside the timed region)."""
+    dist = _dist()
+    if dist is None:
+        return [entry]
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, entry)
+    return out
+
+
 def host_cores():
     """Host cores this process can really use: the affinity mask, capped by the cgroup CPU quota when there is one (a GPU
     box hands a job a share of its CPUs through cpu.max while the affinity mask still shows every core)."""
@@ -180,54 +209,99 @@ def clock_power_probe(step, device, seconds=1.2):
             "how": "amdgpu hwmon (freq1_input, power1_input) read every 0.1 s while the same steps keep running after the timed region"}
 
 
-def cpu_baseline(pset, ek, dk, m, c_gpu, K_gpu, want_seconds=20.0):
-    """Time the reference (or the port) on the host cores over a bounded sample of the SAME items."""
+def _threaded(work, cores):
+    """work(t) for t in range(cores) on a thread pool (ctypes releases the GIL inside the C calls); returns (results, wall s)."""
     from concurrent.futures import ThreadPoolExecutor
-    from oracle import loader
-    cores = host_cores()   # every host core this process may use (affinity mask and cgroup quota); the count is reported
-    n_all = m.shape[0]
-    use_ref = loader.Ref.available()
-    if use_ref:   # calibrate on one pair (30-80 ms per pair per core at -O2), then size for ~want_seconds of CPU work
-        t1 = loader.Ref().time_encaps_decaps(pset, ek[:1].cpu().numpy(), dk[:1].cpu().numpy(), m[:1].cpu().numpy())[0]
-        per_core = max(2, min(512, int(round(want_seconds / max(t1, 1e-3) / cores))))
-    else:
-        per_core = 2000   # the port runs ~0.5 ms per pair
-    per_core = max(1, min(per_core, n_all // cores))
-    take = per_core * cores
-    ekh, dkh, mh = ek[:take].cpu().numpy(), dk[:take].cpu().numpy(), m[:take].cpu().numpy()
-    if use_ref:
-        ref = loader.Ref()
-        kind = "reference"
-
-        def work(t):
-            sl = slice(t * per_core, (t + 1) * per_core)
-            return ref.time_encaps_decaps(pset, ekh[sl], dkh[sl], mh[sl])
-        label = "reference ml_kem.c+sha3.c (gcc -O2) Encaps_internal + KEM_Decaps"
-    else:
-        orc = loader.Oracle()
-        kind = "port"
-
-        def work(t):
-            sl = slice(t * per_core, (t + 1) * per_core)
-            t0 = time.perf_counter()
-            c, K = orc.encaps(pset, ekh[sl], mh[sl])
-            K2, st = orc.decaps(pset, dkh[sl], c)
-            return time.perf_counter() - t0, c, K, int(((K2 == K).all(axis=1) & (st == 0)).sum())
-        label = "oracle/mlkem_oracle.c restatement (gcc -O2) encaps + decaps"
     t0 = time.perf_counter()
     with ThreadPoolExecutor(cores) as ex:
         res = list(ex.map(work, range(cores)))
-    wall = time.perf_counter() - t0
-    pairs = per_core * cores
-    cg, Kg = c_gpu[:pairs].cpu().numpy(), K_gpu[:pairs].cpu().numpy()
-    c_cpu = np.concatenate([r[1] for r in res])
-    K_cpu = np.concatenate([r[2] for r in res])
-    agree = sum(r[3] for r in res)
-    matches_gpu = bool((c_cpu == cg).all() and (K_cpu == Kg).all() and agree == pairs)
-    return {"value": pairs / wall, "unit": "pairs/s", "cores": cores, "kind": kind,
-            "sample": f"{pairs} pairs ({per_core} per thread x {cores} threads) of the benched batch, {label}; "
-                      f"wall {wall:.1f}s; per-core {pairs / sum(r[0] for r in res):.2f} pairs/s",
-            "outputs_match_gpu": matches_gpu}
+    return res, time.perf_counter() - t0
+
+
+def _leg(kind, flags, unit, done, wall, cpu_s, cores, per_core, matches, what):
+    return {"value": done / wall, "unit": unit, "cores": cores, "kind": kind, "flags": flags, "per_core": done / cpu_s,
+            "sample": f"{done} {unit.split('/')[0]} ({per_core} per thread x {cores} threads) of the benched batch, {what}; "
+                      f"wall {wall:.1f}s", "outputs_match_gpu": bool(matches)}
+
+
+def cpu_baseline(pset, ek, dk, m, c_gpu, K_gpu, triples=None, budget=(14.0, 8.0, 4.0)):
+    """the reference at -O2, the reference at its makefile's own flags (-Wall -g, i.e. -O0) and the
+    multi-threaded restatement, each over a bounded sample of the SAME items (sized for ~budget[i] seconds of CPU work in all)
+    and each compared byte for byte with what the GPU produced.  `triples` = (d, z): time KeyGen_internal as well (configs[3])."""
+    from oracle import loader
+    cores = host_cores()   # every host core this process may use (affinity mask and cgroup quota); the count is reported
+    n_all = m.shape[0]
+    unit = "triples/s" if triples else "pairs/s"
+    ops = "KeyGen_internal + Encaps_internal + KEM_Decaps" if triples else "Encaps_internal + KEM_Decaps"
+    legs = {}
+
+    def host_rows(t, take):
+        return t[:take].cpu().numpy()
+
+    def check(take, res):   # res[t] = (seconds, [ek, dk,] c, K, agree)
+        c_cpu = np.concatenate([r[-3] for r in res])
+        K_cpu = np.concatenate([r[-2] for r in res])
+        ok = (c_cpu == host_rows(c_gpu, take)).all() and (K_cpu == host_rows(K_gpu, take)).all() and sum(r[-1] for r in res) == take
+        if triples:
+            ok = ok and (np.concatenate([r[1] for r in res]) == host_rows(ek, take)).all() and \
+                (np.concatenate([r[2] for r in res]) == host_rows(dk, take)).all()
+        return ok
+
+    for name, o0, flags, want in (("reference_O2", False, "gcc -O2", budget[0]), ("reference_O0", True, "gcc -Wall -g (the reference makefile's flags, /root/reference/makefile:2)", budget[1])):
+        if want <= 0 or not loader.Ref.available(o0):
+            continue
+        ref = loader.Ref(o0)
+        if triples and not hasattr(ref.lib, "ref_time_triples"):
+            continue
+        one = (lambda sl: ref.time_triples(pset, dz[0][sl], dz[1][sl], mh[sl])) if triples else \
+              (lambda sl: ref.time_encaps_decaps(pset, ekh[sl], dkh[sl], mh[sl]))
+        # calibrate on one item (30-800 ms per item per core), then size the sample
+        mh = host_rows(m, 1)
+        ekh, dkh = host_rows(ek, 1), host_rows(dk, 1)
+        dz = (host_rows(triples[0], 1), host_rows(triples[1], 1)) if triples else None
+        t1 = one(slice(0, 1))[0]
+        per_core = max(1, min(512, int(round(want / max(t1, 1e-3) / cores)), n_all // cores))
+        take = per_core * cores
+        mh, ekh, dkh = host_rows(m, take), host_rows(ek, take), host_rows(dk, take)
+        dz = (host_rows(triples[0], take), host_rows(triples[1], take)) if triples else None
+        res, wall = _threaded(lambda t: one(slice(t * per_core, (t + 1) * per_core)), cores)
+        legs[name] = _leg("reference", flags, unit, take, wall, sum(r[0] for r in res), cores, per_core, check(take, res),
+                          f"reference ml_kem.c+sha3.c ({flags.split(' (')[0]}) {ops}")
+
+    orc = loader.Oracle()
+    per_core = max(1, min(int(budget[2] * (400 if triples else 1200)), n_all // cores))   # the port runs ~0.5 ms per pair
+    take = per_core * cores
+    mh, ekh, dkh = host_rows(m, take), host_rows(ek, take), host_rows(dk, take)
+    dz = (host_rows(triples[0], take), host_rows(triples[1], take)) if triples else None
+
+    def port_work(t):
+        sl = slice(t * per_core, (t + 1) * per_core)
+        t0 = time.perf_counter()
+        if triples:
+            ek_c, dk_c = orc.keygen(pset, dz[0][sl], dz[1][sl])
+        else:
+            ek_c, dk_c = ekh[sl], dkh[sl]
+        c, K = orc.encaps(pset, ek_c, mh[sl])
+        K2, st = orc.decaps(pset, dk_c, c)
+        return time.perf_counter() - t0, ek_c, dk_c, c, K, int(((K2 == K).all(axis=1) & (st == 0)).sum())
+    res, wall = _threaded(port_work, cores)
+    legs["port"] = _leg("port", "gcc -O2", unit, take, wall, sum(r[0] for r in res), cores, per_core, check(take, res),
+                        f"oracle/mlkem_oracle.c restatement (gcc -O2), one thread per core, {ops}")
+
+    head = dict(legs.get("reference_O2") or legs["port"])
+    head["legs"] = legs
+    head["outputs_match_gpu"] = all(v["outputs_match_gpu"] for v in legs.values())
+    return head
+
+
+def probe_medians(cp):
+    return (cp["sclk_mhz"]["median"], cp["socket_w"]["median"]) if cp else (None, None)
+
+
+def per_gpu_entry(rank, device, units, steps, own_s, ok, cp):
+    clk, pw = probe_medians(cp)
+    return {"rank": rank, "device": device.index, "name": torch.cuda.get_device_name(device), "value": units * steps / own_s,
+            "ms_per_step": 1e3 * own_s / steps, "correct": bool(ok), "sclk_mhz": clk, "socket_w": pw}
 
 
 def run_kem(args, pset, rank, world, device):
@@ -264,10 +338,15 @@ def run_kem(args, pset, rank, world, device):
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize(device)
+    own = time.perf_counter() - t0      # this rank's own time: per_gpu
     barrier(world)
     elapsed = max_over_ranks(time.perf_counter() - t0, world, device)
 
-    # correctness gate (outside the timed region)
+    # shader clock and socket power on EVERY rank, right behind the timed region while all ranks keep stepping together
+    clock_power = clock_power_probe(step, device)
+    barrier(world)
+
+    # correctness gate (outside the timed region), on every rank; reduced over the ranks by the caller
     ok = bool(torch.equal(K, K2)) and int(st.abs().max()) == 0
     ct = c.clone()
     idx = torch.arange(0, n, 1024, device=device)
@@ -276,7 +355,7 @@ def run_kem(args, pset, rank, world, device):
     same = (Kt == K).all(dim=1)
     ok = ok and not bool(same[idx].any()) and int(same.sum()) == n - idx.numel() and int(stt.abs().max()) == 0
 
-    extra = {}
+    extra = {"per_gpu": per_gpu_entry(rank, device, n, args.steps, own, ok, clock_power), "clock_power": clock_power}
     if rank == 0:
         # per-kernel HIP-event timing of TIMING_PASSES more passes (not part of `value`); totals are per pass
         with pkg.kernel_timing() as kt:
@@ -287,15 +366,79 @@ def run_kem(args, pset, rank, world, device):
                 for k, v in kt.rows.items()}
         extra["kernels"] = rows
         extra["chunk_items"] = args.chunk or int(os.environ.get("MLKEM_CHUNK_ITEMS", 1 << 18))
-        if world == 1:
-            extra["clock_power"] = clock_power_probe(step, device)
         if world == 1 and not args.no_cpu:
             if shared:   # the reference has no shared-key path: every pair pays for the full key handling
                 extra["cpu_baseline"] = cpu_baseline(pset, ek[:1].expand(n, -1), dk[:1].expand(n, -1), m, c, K)
             else:
-                extra["cpu_baseline"] = cpu_baseline(pset, ek, dk, m, c, K)
+                extra["cpu_baseline"] = cpu_baseline(pset, ek, dk, m, c, K, triples=(d, z) if timed_keygen else None,
+                                                     budget=args.cpu_budget)
     eng.close()
     return elapsed, ok, extra
+
+
+def run_kem_inproc(args, pset, members):
+    """The same per-member workload in ONE process: mlkem_{encaps,decaps}_multi_dev, member r on device r % ndev with its own
+    2^20-item shard (items r*batch ...), own stream and engine context; no exchange between members.  Per-member times come
+    from events on the members' own streams."""
+    pkg = ge.load_package()
+    n = args.batch
+    ndev = torch.cuda.device_count()
+    devices = [r % ndev for r in range(members)]
+    mm = pkg.MLKEMMulti(pset, devices=devices, chunk_items=args.chunk)
+    devs = [torch.device("cuda", dv) for dv in devices]
+    d, z, m = ([device_seeds(lbl, r * n, n, devs[r]) for r in range(members)] for lbl in ("mlkem-bench-d", "mlkem-bench-z", "mlkem-bench-m"))
+    ek, dk = mm.keygen_dev(d, z)       # untimed
+    c = [torch.empty((n, mm.c_len), dtype=torch.uint8, device=dv) for dv in devs]
+    K, K2 = ([torch.empty((n, 32), dtype=torch.uint8, device=dv) for dv in devs] for _ in range(2))
+    st = [torch.empty(n, dtype=torch.int32, device=dv) for dv in devs]
+
+    def step():
+        mm.encaps_dev(ek, m, c=c, K=K)
+        mm.decaps_dev(dk, c, K=K2, status=st)
+
+    for _ in range(args.warmup):
+        step()
+    mm.sync()
+    ext = mm.streams()
+    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(members)]
+    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(members)]
+    t0 = time.perf_counter()
+    for r in range(members):
+        ev0[r].record(ext[r])
+    for _ in range(args.steps):
+        step()
+    for r in range(members):
+        ev1[r].record(ext[r])
+    mm.sync()
+    elapsed = time.perf_counter() - t0
+    own = [ev0[r].elapsed_time(ev1[r]) * 1e-3 for r in range(members)]
+    cps = {}
+    for dv in sorted(set(devices)):   # one probe per distinct device while ALL members keep running
+        cps[dv] = clock_power_probe(lambda: (step(), mm.sync()), torch.device("cuda", dv))
+    ok_all, per_gpu = True, []
+    for r in range(members):
+        ok = bool(torch.equal(K[r], K2[r])) and int(st[r].abs().max()) == 0
+        per_gpu.append(per_gpu_entry(r, devs[r], n, args.steps, own[r], ok, cps[devices[r]]))
+        ok_all = ok_all and ok
+    ct = [t.clone() for t in c]
+    idx = [torch.arange(0, n, 1024, device=dv) for dv in devs]
+    for r in range(members):
+        ct[r][idx[r], (idx[r] * 13) % mm.c_len] ^= 2
+    Kt, stt = mm.decaps_dev(dk, ct)
+    mm.sync()
+    for r in range(members):
+        same = (Kt[r] == K[r]).all(dim=1)
+        ok = not bool(same[idx[r]].any()) and int(same.sum()) == n - idx[r].numel() and int(stt[r].abs().max()) == 0
+        per_gpu[r]["correct"] = per_gpu[r]["correct"] and ok
+        ok_all = ok_all and ok
+    with pkg.kernel_timing() as kt:
+        step()
+        mm.sync()
+    kernels = {k: {"ms_total": v[0], "launches": v[1], "ms_avg": v[0] / max(v[1], 1)} for k, v in kt.rows.items()}
+    mm.close()
+    return elapsed, ok_all, {"per_gpu_all": per_gpu, "clock_power": cps[devices[0]], "kernels": kernels, "devices": devices,
+                             "kernel_table_units": n * members,   # the kernel table covers one step of ALL members
+                             "chunk_items": args.chunk or int(os.environ.get("MLKEM_CHUNK_ITEMS", 1 << 18))}
 
 
 def run_ntt(args, rank, world, device):
@@ -321,10 +464,13 @@ def run_ntt(args, rank, world, device):
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize(device)
+    own = time.perf_counter() - t0
     barrier(world)
     elapsed = max_over_ranks(time.perf_counter() - t0, world, device)
+    clock_power = clock_power_probe(step, device)
+    barrier(world)
     ok = bool(torch.equal(f, f2)) and int(fh.min()) >= 0 and int(fh.max()) < 3329
-    extra = {}
+    extra = {"per_gpu": per_gpu_entry(rank, device, n, args.steps, own, ok, clock_power), "clock_power": clock_power}
     if rank == 0:
         with pkg.kernel_timing() as kt:
             for _ in range(TIMING_PASSES):
@@ -332,19 +478,29 @@ def run_ntt(args, rank, world, device):
             torch.cuda.synchronize(device)
         extra["kernels"] = {k: {"ms_total": v[0] / TIMING_PASSES, "launches": v[1] // TIMING_PASSES, "ms_avg": v[0] / max(v[1], 1)}
                             for k, v in kt.rows.items()}
-        if world == 1:
-            extra["clock_power"] = clock_power_probe(step, device)
         if world == 1 and not args.no_cpu:
             from oracle import loader
             orc = loader.Oracle()
-            sample = f[:20000].cpu().numpy().view(np.uint16)
-            t0 = time.perf_counter()
-            h = orc.ntt(sample)
-            back = orc.intt(h)
-            dt = time.perf_counter() - t0
-            extra["cpu_baseline"] = {"value": sample.shape[0] / dt, "unit": "polys/s", "cores": 1, "kind": "port",
-                                     "sample": "20000 polynomials NTT+InverseNTT, oracle/mlkem_oracle.c (gcc -O2), 1 thread",
-                                     "outputs_match_gpu": bool((h == fh[:20000].cpu().numpy().view(np.uint16)).all() and (back == sample).all())}
+            cores = host_cores()
+            per_core = 4000
+            sample = f[:per_core * cores].cpu().numpy().view(np.uint16)
+
+            def work(t):
+                sl = slice(t * per_core, (t + 1) * per_core)
+                t0 = time.perf_counter()
+                h = orc.ntt(sample[sl])
+                back = orc.intt(h)
+                return time.perf_counter() - t0, h, back
+            res, wall = _threaded(work, cores)
+            h = np.concatenate([r[1] for r in res])
+            back = np.concatenate([r[2] for r in res])
+            done = sample.shape[0]
+            extra["cpu_baseline"] = {"value": done / wall, "unit": "polys/s", "cores": cores, "kind": "port", "flags": "gcc -O2",
+                                     "per_core": done / sum(r[0] for r in res),
+                                     "sample": f"{done} polynomials ({per_core} per thread x {cores} threads) NTT+InverseNTT, "
+                                               f"oracle/mlkem_oracle.c (the reference's NTT spends half its time recomputing zeta: "
+                                               f"SURVEY a8); wall {wall:.1f}s",
+                                     "outputs_match_gpu": bool((h == fh[:done].cpu().numpy().view(np.uint16)).all() and (back == sample).all())}
     eng.close()
     return elapsed, ok, extra
 
@@ -392,42 +548,49 @@ def entry(workload, args, elapsed, ok, extra, world):
     value = units / elapsed
     ms_step = 1e3 * elapsed / args.steps
     algo = ALGO_BYTES[workload]
-    achieved = value / world * algo / 1e9          # per-GPU algorithmic GB/s
+    whole = value / world * algo / 1e9             # per-GPU algorithmic GB/s of the whole pass
     kernels = extra.get("kernels", {})
     dom = max(kernels.items(), key=lambda kv: kv[1]["ms_total"])[0] if kernels else None
-    if workload == "ntt" and dom:
-        # NTT-only: each of the two kernels (forward, inverse) handles a whole unit half: 1024 algorithmic bytes per
-        # polynomial and launch; the roofline entry is the dominant kernel's, from its own HIP-event duration.
-        per_launch = 1024.0 * args.batch
-        achieved = per_launch / (kernels[dom]["ms_avg"] * 1e-3) / 1e9
-        scope = "dominant kernel %s: 1024 B/polynomial x %d polynomials per launch / its average HIP-event duration; " \
-                "whole step (fwd+inv, 2048 B/poly) = %.1f GB/s" % (dom, args.batch, value / world * algo / 1e9)
-    else:
-        scope = "whole pass (all kernels of one step, no single kernel covers a unit); algorithmic bytes = %d B/unit x %d units " \
-                "per step / step time" % (algo, args.batch)
+    achieved, scope = whole, "whole pass: algorithmic bytes = %d B/unit x %d units per step / step time" % (algo, args.batch)
+    if dom:
+        # The dominant kernel by the algorithmic-bytes rule: SURVEY 8d's per-unit bytes x the units one launch stands for / the
+        # kernel's average launch duration (HIP events on its launch stream).  NTT-only: each of the two kernels handles one
+        # direction = 1024 B per polynomial, all `batch` polynomials per launch.  Full KEM: a step issues `launches` launches
+        # of the dominant kernel over the batch, so one launch stands for batch / launches units.
+        launches = max(1, kernels[dom]["launches"])
+        per_unit = 1024.0 if workload == "ntt" else float(algo)
+        units_per_launch = args.batch if workload == "ntt" else extra.get("kernel_table_units", args.batch) / launches
+        achieved = per_unit * units_per_launch / (kernels[dom]["ms_avg"] * 1e-3) / 1e9
+        scope = "dominant kernel %s: %g B/unit x %g units per launch (%d launches per step) / its average HIP-event duration %.4f ms" % (
+            dom, per_unit, units_per_launch, launches, kernels[dom]["ms_avg"])
     roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": None, "scope": scope,
+                "whole_pass": {"achieved": whole, "frac": whole / HBM_PEAK_GBS,
+                               "scope": "all kernels of one step: %d B/unit x %d units / step time" % (algo, args.batch)},
                 "dominant_kernel": dom,
                 "dominant_kernel_ms_avg": kernels[dom]["ms_avg"] if dom else None,
                 "dominant_kernel_share": kernels[dom]["ms_total"] / sum(k["ms_total"] for k in kernels.values()) if dom else None}
     # HBM traffic from the PMC counters is collected off-line (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE cannot run inside
     # this process).  The committed summary is attached only when it was measured on THIS build (same source hash), for
     # this workload, batch and chunking; otherwise traffic stays null.
-    tpath = os.path.join(ROOT, "profiles", "r02_pmc_traffic_%s.json" % workload)
-    if os.path.exists(tpath):
+    tpath = next((q for q in (os.path.join(ROOT, "profiles", "%s_pmc_traffic_%s.json" % (rnd, workload)) for rnd in ("r03", "r02"))
+                  if os.path.exists(q)), None)
+    if tpath:
         t = json.load(open(tpath))
         if t.get("source_id") == source_id() and t.get("batch") == args.batch:
             roofline["traffic"] = t["hbm_bytes_per_step_corrected"]
-            roofline["traffic_note"] = "bytes per step from %s (git %s, source_id %s): (2*FETCH_SIZE + WRITE_SIZE)*1024; raw = %.3g" % (
+            roofline["traffic_note"] = "bytes per STEP (all kernels) from %s (git %s, source_id %s): (2*FETCH_SIZE + WRITE_SIZE)*1024; raw = %.3g" % (
                 os.path.relpath(tpath, ROOT), t.get("git_head", "?"), t["source_id"], t["hbm_bytes_per_step_raw"])
+            if dom and t.get("per_kernel", {}).get(dom):
+                roofline["dominant_kernel_traffic_per_launch"] = t["per_kernel"][dom]["bytes_per_launch_corrected"]
         else:
             roofline["traffic_note"] = "%s was measured on another build (source_id %s != %s) or batch: not attached" % (
                 os.path.relpath(tpath, ROOT), t.get("source_id"), source_id())
     if workload in ("kem512", "kem768", "kem1024") and dom == "k_sample_main":
         # the dominant kernel's own HBM bytes per launch: per item it reads rho and r (32 B each) and
-        # writes the k x k matrix (A_POLY_BYTES per polynomial) and the PRF rows (128 B, 192 B for eta = 3)
+        # writes the k x k matrix (512 B per polynomial) and the PRF rows (128 B, 192 B for eta = 3)
         k = {"kem512": 2, "kem768": 3, "kem1024": 4}[workload]
-        per_item = 64 + extra.get("a_poly_bytes", 512) * k * k + (2 * k + 1) * 128 + (k * 64 if k == 2 else 0)
+        per_item = 64 + 512 * k * k + (2 * k + 1) * 128 + (k * 64 if k == 2 else 0)
         chunk = min(extra.get("chunk_items") or (1 << 18), args.batch)
         roofline["dominant_kernel_bytes_per_launch"] = per_item * chunk
         roofline["dominant_kernel_GBps"] = per_item * chunk / (kernels[dom]["ms_avg"] * 1e-3) / 1e9
@@ -440,8 +603,8 @@ def entry(workload, args, elapsed, ok, extra, world):
                                "keccak_lane_ops_per_s": value / world * keccak_ops,
                                "peak_lane_ops_per_s": VALU_PEAK_LANE_OPS,
                                "frac_keccak_only": value / world * keccak_ops / VALU_PEAK_LANE_OPS,
-                               "note": "the pass runs into the socket power limit (rocm-smi: ~1340 W, shader clock ~2.07 GHz instead of "
-                                       "2.4 GHz; DESIGN.md section 5, profiles/r01_clock_power_watch.txt, profiles/r01_power_ubench.txt)"}
+                               "note": "the pass runs into the socket power limit (clock_power below: shader clock well under the "
+                                       "nominal 2.4 GHz at ~1.33 kW; DESIGN.md section 5)"}
     if extra.get("clock_power"):
         roofline["clock_power"] = extra["clock_power"]
     return {"value": value, "ms_per_step": ms_step, "correct": ok, "roofline": roofline, "kernels": kernels}
@@ -462,10 +625,15 @@ def main():
     ap.add_argument("--rehearse", action="store_true",
                     help="N > 1 ranks on fewer GPUs: ranks share the visible GPU(s), barrier over gloo (automatic when the node "
                          "has fewer GPUs than ranks)")
+    ap.add_argument("--inproc", action="store_true",
+                    help="one process, --gpus members through mlkem_*_multi_dev (member r on device r %% visible devices)")
     args = ap.parse_args()
     if args.steps is None:
         args.steps = 200 if args.workload == "ntt" else 20
+    args.cpu_budget = (14.0, 8.0, 4.0)   # CPU-seconds of work for the reference -O2 / reference -O0 / port legs
 
+    if args.inproc:
+        return main_inproc(args)
     rank, world, local = dist_setup(args.gpus, args.rehearse)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the engine has no CPU fallback")
@@ -479,22 +647,28 @@ def main():
     also = {}
     if world == 1 and args.workload == "kem768" and not args.no_also:
         # BASELINE configs[1] and configs[3] in the same process, so that they are driver-observed too (not the headline:
-        # `value` above is configs[2]); same timing discipline, their own step counts
+        # `value` above is configs[2]); same timing discipline, their own step counts, their own CPU legs
         for wl2, steps2 in (("ntt", 200), ("kem1024", 10)):
             a2 = argparse.Namespace(**vars(args))
-            a2.workload, a2.steps, a2.warmup, a2.no_cpu = wl2, steps2, 2, True
+            a2.workload, a2.steps, a2.warmup = wl2, steps2, 2
+            a2.cpu_budget = (8.0, 0.0, 2.0)   # configs[3]: reference -O2 and port legs (the -O0 leg is on the headline)
             el2, ok2, ex2 = run_workload(wl2, a2, rank, world, device)
             e2 = entry(wl2, a2, el2, ok2, ex2, world)
             m2 = WORKLOAD_META[wl2]
             e2.update({"metric": m2[0], "unit": m2[1], "steps": steps2, "warmup": 2, "config": {"workload": m2[2] % a2.batch}})
+            if "cpu_baseline" in ex2:
+                e2["cpu_baseline"] = ex2["cpu_baseline"]
             also[wl2] = e2
             ok = ok and ok2
             torch.cuda.empty_cache()
 
+    # the gate of the whole job: every rank's bytes must be right; per-rank results travel to rank 0 over the control plane
+    ok = all_ranks_ok(ok, device)
+    per_gpu = gather_per_gpu(extra["per_gpu"])
     if _dist() is not None:
         _dist().destroy_process_group()
     if rank != 0:
-        return
+        sys.exit(0 if ok else 3)
     e = entry(args.workload, args, elapsed, ok, extra, world)
     par = "shard%d (no collectives)" % world
     if SHARED_GPU:
@@ -503,11 +677,34 @@ def main():
             "ms_per_step": e["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype,
             "data": "synthetic", "config": {"workload": wl % args.batch, "batch_per_gpu": args.batch, "parallelism": par,
                                             "chunk_items": extra.get("chunk_items")},
-            "correct": ok, "roofline": e["roofline"], "kernels": e["kernels"]}
+            "correct": ok, "per_gpu": per_gpu, "roofline": e["roofline"], "kernels": e["kernels"]}
     if "cpu_baseline" in extra:
         line["cpu_baseline"] = extra["cpu_baseline"]
     if also:
         line["also"] = also
+    print(json.dumps(line))
+    if not ok:
+        sys.exit(3)
+
+
+def main_inproc(args):
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the engine has no CPU fallback")
+    if args.workload != "kem768":
+        raise SystemExit("--inproc runs BASELINE configs[4]'s workload (kem768)")
+    members = max(1, args.gpus)
+    elapsed, ok, extra = run_kem_inproc(args, 768, members)
+    metric, unit, wl, _ = WORKLOAD_META["kem768"]
+    ndev = len(set(extra["devices"]))
+    e = entry("kem768", args, elapsed, ok, extra, members)
+    par = "inproc shard%d: one process, %d members on %d device(s) through mlkem_*_multi_dev (no collectives)" % (members, members, ndev)
+    if ndev < members:
+        par += "; REHEARSAL: members share devices - not a scaling measurement"
+    line = {"metric": metric, "value": e["value"], "unit": unit, "n_gpus": members, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": e["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": KEM_DTYPE,
+            "data": "synthetic", "config": {"workload": wl % args.batch, "batch_per_gpu": args.batch, "parallelism": par,
+                                            "chunk_items": extra.get("chunk_items"), "member_devices": extra["devices"]},
+            "correct": ok, "per_gpu": extra["per_gpu_all"], "roofline": e["roofline"], "kernels": e["kernels"]}
     print(json.dumps(line))
     if not ok:
         sys.exit(3)

@@ -40,7 +40,8 @@ ABI_SYMBOLS = (
     "mlkem_selftest_count", "mlkem_selftest", "mlkem_host_release", "mlkem_host_register", "mlkem_host_unregister",
     "mlkem_multi_create", "mlkem_multi_destroy", "mlkem_multi_members", "mlkem_multi_device", "mlkem_shard_range",
     "mlkem_keygen_multi", "mlkem_encaps_multi", "mlkem_decaps_multi",
-    "mlkem_keygen_multi_dev", "mlkem_encaps_multi_dev", "mlkem_decaps_multi_dev", "mlkem_multi_sync",
+    "mlkem_keygen_multi_dev", "mlkem_encaps_multi_dev", "mlkem_decaps_multi_dev", "mlkem_multi_sync", "mlkem_multi_stream",
+    "mlkem_vector_multiply_dev", "mlkem_poly_add_dev", "mlkem_poly_sub_dev",
 )
 SHIM_SYMBOLS = ("init", "KEM_KeyGen", "KEM_Encaps", "KEM_Decaps", "ml_errno", "sha3_b", "sha3_h", "sha3_s", "h2b", "b2h",
                 "SampleNTT", "SamplePolyCBD", "NTT", "InverseNTT")
@@ -135,6 +136,11 @@ def load_library():
     L.mlkem_encaps_multi_dev.argtypes = [vp, i32, C.POINTER(sz), pp, pp, pp, pp]
     L.mlkem_decaps_multi_dev.argtypes = [vp, i32, C.POINTER(sz), pp, pp, pp, pp]
     L.mlkem_multi_sync.argtypes = [vp]
+    L.mlkem_multi_stream.argtypes = [vp, i32]
+    L.mlkem_multi_stream.restype = vp
+    L.mlkem_vector_multiply_dev.argtypes = [vp, i32, sz, vp, vp, vp, vp]
+    L.mlkem_poly_add_dev.argtypes = [vp, sz, vp, vp, vp, vp]
+    L.mlkem_poly_sub_dev.argtypes = [vp, sz, vp, vp, vp, vp]
     _lib = L
     return L
 
@@ -384,6 +390,35 @@ class MLKEM:
                                                      self._stream()))
         return out
 
+    def vector_multiply(self, u, v):
+        """VectorMultiply (ml_kem.c:618): u, v [n,k,256] -> [n,256] = sum_i MultiplyNTTs(u[:,i], v[:,i])."""
+        torch = self.torch
+        u, v = (t.view(torch.int16) if t.dtype == torch.uint16 else t for t in (torch.as_tensor(u), torch.as_tensor(v)))
+        u = u.to(device=self.device, dtype=torch.int16).contiguous()
+        v = v.to(device=self.device, dtype=torch.int16).contiguous()
+        if u.dim() != 3 or u.shape != v.shape or u.shape[2] != 256 or not 1 <= u.shape[1] <= 4:
+            raise MLKEMError(-101, f"vector_multiply expects two [n, k, 256] operands with k in 1..4, got {tuple(u.shape)} and {tuple(v.shape)}")
+        out = self._out(u.shape[0], 256, torch.int16)
+        self._check(self.lib.mlkem_vector_multiply_dev(self._ctx, u.shape[1], u.shape[0], u.data_ptr(), v.data_ptr(), out.data_ptr(),
+                                                       self._stream()))
+        return out
+
+    def _addsub(self, fn, a, b):
+        a, b = self._poly(a), self._poly(b)
+        if a.shape != b.shape:
+            raise MLKEMError(-101, "operands differ in shape")
+        out = self.torch.empty_like(a)
+        self._check(fn(self._ctx, a.numel(), a.data_ptr(), b.data_ptr(), out.data_ptr(), self._stream()))
+        return out
+
+    def poly_add(self, a, b):
+        """PolyAddition (ml_kem.c:580): [n,256] + [n,256] coefficient-wise mod q."""
+        return self._addsub(self.lib.mlkem_poly_add_dev, a, b)
+
+    def poly_sub(self, a, b):
+        """PolySubtraction (ml_kem.c:599)."""
+        return self._addsub(self.lib.mlkem_poly_sub_dev, a, b)
+
     def sample_ntt(self, seeds34):
         """SampleNTT (ml_kem.c:189): [n,34] -> [n,256]."""
         s = self._dev(seeds34, self.torch.uint8, 34)
@@ -519,6 +554,9 @@ class MLKEM:
     NTT = ntt
     InverseNTT = intt
     MultiplyNTTs = multiply_ntts
+    VectorMultiply = vector_multiply
+    PolyAddition = poly_add
+    PolySubtraction = poly_sub
     SampleNTT = sample_ntt
     SamplePolyCBD = sample_cbd
     PRF = prf
@@ -549,6 +587,7 @@ class MLKEMMulti:
 
     def close(self):
         if getattr(self, "_mm", None):
+            self._ext = None
             self.lib.mlkem_multi_destroy(self._mm)
             self._mm = None
 
@@ -620,27 +659,62 @@ class MLKEMMulti:
         return [torch.empty((n, last) if last is not None else (n,), dtype=dtype or torch.uint8, device=torch.device("cuda", dv))
                 for n, dv in zip(ns, self.devices)]
 
+    # Stream discipline of the device-resident calls.  The members enqueue on their own non-blocking streams (C-ABI:
+    # mlkem_multi_stream), torch allocates and produces on ITS current stream.  Around every call the wrapper therefore
+    #   1. makes each member stream wait for torch's current stream on that device (the producers of the input shards and
+    #      whatever last used the memory the caching allocator hands out for the outputs),
+    #   2. tells the allocator that inputs and outputs are in use on the member stream (record_stream), so that dropping a
+    #      tensor before sync() cannot hand its memory to other work while the member still reads or writes it.
+    # Results are ordered for torch by sync() (or by streams()[r] events).
+    def streams(self):
+        """torch views (ExternalStream) of the members' HIP streams, one per member."""
+        torch = self.torch
+        if getattr(self, "_ext", None) is None:
+            ext = []
+            for r, dv in enumerate(self.devices):
+                h = self.lib.mlkem_multi_stream(self._mm, r)
+                if not h:
+                    raise MLKEMError(-100, "member stream unavailable [" + self.lib.mlkem_last_hip_error().decode() + "]")
+                ext.append(torch.cuda.ExternalStream(h, device=torch.device("cuda", dv)))
+            self._ext = ext
+        return self._ext
+
+    def _order(self, *tensor_lists):
+        torch = self.torch
+        for r, (dv, ext) in enumerate(zip(self.devices, self.streams())):
+            ext.wait_stream(torch.cuda.current_stream(torch.device("cuda", dv)))
+            for ts in tensor_lists:
+                ts[r].record_stream(ext)
+
     def keygen_dev(self, d, z):
-        """shards d[r], z[r] [n_r, 32] on device r -> ek[r], dk[r]; enqueued, call sync() before reading."""
+        """shards d[r], z[r] [n_r, 32] on device r -> ek[r], dk[r].  Enqueued on the member streams behind torch's current
+        streams; call sync() (or wait on streams()[r]) before reading the outputs from another stream."""
         ns_c, ns = self._sizes(d, z)
         ek, dk = self._empty(ns, self.ek_len), self._empty(ns, self.dk_len)
-        self._check(self.lib.mlkem_keygen_multi_dev(self._mm, self.param_set, ns_c, self._shards(d, 32), self._shards(z, 32),
-                                                    self._shards(ek, self.ek_len), self._shards(dk, self.dk_len)))
+        pd, pz, pek, pdk = self._shards(d, 32), self._shards(z, 32), self._shards(ek, self.ek_len), self._shards(dk, self.dk_len)
+        self._order(d, z, ek, dk)
+        self._check(self.lib.mlkem_keygen_multi_dev(self._mm, self.param_set, ns_c, pd, pz, pek, pdk))
         return ek, dk
 
-    def encaps_dev(self, ek, m):
+    def encaps_dev(self, ek, m, c=None, K=None):
         ns_c, ns = self._sizes(m, ek)
-        c, K = self._empty(ns, self.c_len), self._empty(ns, 32)
-        self._check(self.lib.mlkem_encaps_multi_dev(self._mm, self.param_set, ns_c, self._shards(ek, self.ek_len), self._shards(m, 32),
-                                                    self._shards(c, self.c_len), self._shards(K, 32)))
+        c = self._empty(ns, self.c_len) if c is None else c
+        K = self._empty(ns, 32) if K is None else K
+        pek, pm, pc, pK = self._shards(ek, self.ek_len), self._shards(m, 32), self._shards(c, self.c_len), self._shards(K, 32)
+        self._sizes(m, c, K)
+        self._order(ek, m, c, K)
+        self._check(self.lib.mlkem_encaps_multi_dev(self._mm, self.param_set, ns_c, pek, pm, pc, pK))
         return c, K
 
-    def decaps_dev(self, dk, c):
+    def decaps_dev(self, dk, c, K=None, status=None):
         ns_c, ns = self._sizes(c, dk)
-        K, st = self._empty(ns, 32), self._empty(ns, None, self.torch.int32)
-        self._check(self.lib.mlkem_decaps_multi_dev(self._mm, self.param_set, ns_c, self._shards(dk, self.dk_len),
-                                                    self._shards(c, self.c_len), self._shards(K, 32),
-                                                    self._shards(st, None, self.torch.int32)))
+        K = self._empty(ns, 32) if K is None else K
+        st = self._empty(ns, None, self.torch.int32) if status is None else status
+        pdk, pc, pK = self._shards(dk, self.dk_len), self._shards(c, self.c_len), self._shards(K, 32)
+        pst = self._shards(st, None, self.torch.int32)
+        self._sizes(c, K, st)
+        self._order(dk, c, K, st)
+        self._check(self.lib.mlkem_decaps_multi_dev(self._mm, self.param_set, ns_c, pdk, pc, pK, pst))
         return K, st
 
     def sync(self):

@@ -388,6 +388,67 @@ __global__ void __launch_bounds__(WAVE * ARITH_WAVES) k_basemul_batch(size_t n, 
     }
 }
 
+// VectorMultiply (ml_kem.c:618-638): w = sum_{i<k} MultiplyNTTs(u[i], v[i]), every partial sum reduced like the
+// reference's PolyAddition does (ml_kem.c:580-592) -- the k-term accumulate the K-PKE kernels run fused, as a stand-alone
+// entry for row-level parity.  u, v : [n][k][256], any 12-bit values; w : [n][256] canonical.
+__global__ void __launch_bounds__(WAVE * ARITH_WAVES) k_vecmul_batch(size_t n, int k, const uint16_t* __restrict__ u, const uint16_t* __restrict__ v,
+                                                                     uint16_t* __restrict__ w) {
+    __shared__ __attribute__((aligned(16))) float vh_all[ARITH_WAVES][256];
+    __shared__ __attribute__((aligned(16))) float vg_all[ARITH_WAVES][128];
+    const int wv = (int)(threadIdx.x >> 6);
+    NttTwiddlesF tw;
+    load_twiddles_f(tw);
+    const size_t stride = (size_t)gridDim.x * ARITH_WAVES;
+    for (size_t p = (size_t)blockIdx.x * ARITH_WAVES + wv; p < n; p += stride) {
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < k; i++) {
+            float av[4], bv[4];
+            load_poly_nat_f12(u + (p * (size_t)k + (size_t)i) * 256, av);
+            load_poly_nat_f12(v + (p * (size_t)k + (size_t)i) * 256, bv);
+#pragma unroll
+            for (int m = 0; m < 4; m++) bv[m] = fred(bv[m]);
+            stash_vhat_f(vh_all[wv], vg_all[wv], bv, tw);
+            wave_lds_fence();
+            basemul_acc_f(acc, av, vh_all[wv], vg_all[wv]);   // acc stays reduced: |acc| <= 1665
+            wave_lds_fence();
+        }
+        int o[4];
+#pragma unroll
+        for (int m = 0; m < 4; m++) o[m] = fcanon(acc[m]);
+        store_poly_nat(w + p * 256, o);
+    }
+}
+
+// PolyAddition / PolySubtraction (ml_kem.c:580-592 / :599-613) coefficient by coefficient over n uint16 values, inputs
+// taken mod 2^12 like the reference's `union integer.t`:
+//   add: (u + v) % Q                         (u + v <= 8190: at most two subtractions of Q)
+//   sub: u < v ? Q - (v - u) : u - v         stored into the 12-bit field, i.e. & 0xFFF (only differs for v - u > Q)
+// Streaming kernel, 8 values (16 B) per lane and iteration; in-place allowed.
+__device__ __forceinline__ unsigned poly_add1(unsigned a, unsigned b) {
+    unsigned s = (a & 0xFFFu) + (b & 0xFFFu);
+    s -= s >= (unsigned)KQ ? (unsigned)KQ : 0u;
+    s -= s >= (unsigned)KQ ? (unsigned)KQ : 0u;
+    return s;
+}
+__device__ __forceinline__ unsigned poly_sub1(unsigned a, unsigned b) {
+    a &= 0xFFFu; b &= 0xFFFu;
+    return (a < b ? (unsigned)KQ - (b - a) : a - b) & 0xFFFu;
+}
+template <bool SUB>
+__global__ void __launch_bounds__(256) k_poly_addsub(size_t n, const uint16_t* __restrict__ a, const uint16_t* __restrict__ b, uint16_t* __restrict__ out) {
+    const size_t groups = n / 8, stride = (size_t)gridDim.x * blockDim.x;
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    auto f = [](unsigned x, unsigned y) { return SUB ? poly_sub1(x, y) : poly_add1(x, y); };
+    auto f2 = [&f](uint32_t x, uint32_t y) { return f(x & 0xFFFFu, y & 0xFFFFu) | (f(x >> 16, y >> 16) << 16); };
+    for (size_t g = t; g < groups; g += stride) {
+        const uint4 x = reinterpret_cast<const uint4*>(a)[g], y = reinterpret_cast<const uint4*>(b)[g];
+        uint4 o;
+        o.x = f2(x.x, y.x); o.y = f2(x.y, y.y); o.z = f2(x.z, y.z); o.w = f2(x.w, y.w);
+        reinterpret_cast<uint4*>(out)[g] = o;
+    }
+    for (size_t i = groups * 8 + t; i < n; i += stride) out[i] = (uint16_t)f(a[i], b[i]);
+}
+
 // SamplePolyCBD (ml_kem.c:253-275): bytes [n][64*eta] -> canonical uint16 polynomials
 template <int ETA>
 __global__ void __launch_bounds__(WAVE * ARITH_WAVES) k_cbd_batch(size_t n, const uint8_t* __restrict__ bytes, uint16_t* __restrict__ out) {

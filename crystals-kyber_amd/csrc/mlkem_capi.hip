@@ -14,8 +14,12 @@
 #include <cstdlib>
 #include <cstring>
 #include <string.h>
+#include <condition_variable>
+#include <functional>
 #include <map>
+#include <memory>
 #include <mutex>
+#include <new>
 #include <string>
 #include <thread>
 #include <vector>
@@ -202,6 +206,7 @@ int mlkem_timing_end(char* labels, double* total_ms, int* counts, int max) {
     LaunchRecorder* rec = launch_recorder();
     if (!rec) return MLKEM_ERR_ARG;
     launch_recorder() = nullptr;
+    const bool failed = rec->failed;
     int rows = 0;
     for (auto& r : rec->recs) {
         float ms = 0.f;
@@ -223,7 +228,7 @@ int mlkem_timing_end(char* labels, double* total_ms, int* counts, int max) {
         counts[k] += 1;
     }
     delete rec;
-    return rows;
+    return failed ? MLKEM_ERR_NO_DEVICE : rows;   // incomplete rows are worse than none
 }
 
 // ---- device-pointer KEM ------------------------------------------------------------------------------
@@ -344,6 +349,24 @@ int mlkem_intt_dev(mlkem_ctx* ctx, size_t n, const uint16_t* fh, uint16_t* f, vo
 int mlkem_multiply_ntts_dev(mlkem_ctx* ctx, size_t n, const uint16_t* a, const uint16_t* b, uint16_t* h, void* stream) {
     if (!ctx_ok(ctx) || (n && (!a || !b || !h)) || !aligned16(a) || !aligned16(b) || !aligned16(h)) return MLKEM_ERR_ARG;
     basemul_launch(static_cast<hipStream_t>(stream), n, a, b, h);
+    HIP_TRY(hipGetLastError());
+    return MLKEM_OK;
+}
+int mlkem_vector_multiply_dev(mlkem_ctx* ctx, int k, size_t n, const uint16_t* u, const uint16_t* v, uint16_t* w, void* stream) {
+    if (!ctx_ok(ctx) || k < 1 || k > 4 || (n && (!u || !v || !w)) || !aligned16(u) || !aligned16(v) || !aligned16(w)) return MLKEM_ERR_ARG;
+    if (n) vecmul_launch(static_cast<hipStream_t>(stream), k, n, u, v, w);
+    HIP_TRY(hipGetLastError());
+    return MLKEM_OK;
+}
+int mlkem_poly_add_dev(mlkem_ctx* ctx, size_t n_values, const uint16_t* u, const uint16_t* v, uint16_t* z, void* stream) {
+    if (!ctx_ok(ctx) || (n_values && (!u || !v || !z)) || !aligned16(u) || !aligned16(v) || !aligned16(z)) return MLKEM_ERR_ARG;
+    if (n_values) poly_addsub_launch(static_cast<hipStream_t>(stream), false, n_values, u, v, z);
+    HIP_TRY(hipGetLastError());
+    return MLKEM_OK;
+}
+int mlkem_poly_sub_dev(mlkem_ctx* ctx, size_t n_values, const uint16_t* u, const uint16_t* v, uint16_t* z, void* stream) {
+    if (!ctx_ok(ctx) || (n_values && (!u || !v || !z)) || !aligned16(u) || !aligned16(v) || !aligned16(z)) return MLKEM_ERR_ARG;
+    if (n_values) poly_addsub_launch(static_cast<hipStream_t>(stream), true, n_values, u, v, z);
     HIP_TRY(hipGetLastError());
     return MLKEM_OK;
 }
@@ -524,8 +547,10 @@ void par_memcpy(void* dst, const void* src, size_t bytes) {
     for (auto& x : th) x.join();
 }
 
-// is [p, p + bytes) host memory the DMA engines can address directly (pinned or registered)?
-bool host_pinned(const void* p) {
+// is [p, p + bytes) host memory the DMA engines can address directly (pinned or registered)?  The first AND the last byte
+// must be pinned host memory, and where the runtime reports the allocation's range the whole span must lie inside it: a
+// buffer that is only partly registered is staged like a pageable one.
+bool host_pinned_byte(const void* p) {
     hipPointerAttribute_t a;
     memset(&a, 0, sizeof a);
     if (hipPointerGetAttributes(&a, p) != hipSuccess) {
@@ -533,6 +558,19 @@ bool host_pinned(const void* p) {
         return false;
     }
     return a.type == hipMemoryTypeHost;
+}
+bool host_pinned(const void* p, size_t bytes) {
+    if (!p || bytes == 0) return false;
+    const uint8_t* b = static_cast<const uint8_t*>(p);
+    if (!host_pinned_byte(b) || !host_pinned_byte(b + bytes - 1)) return false;
+    hipDeviceptr_t base = nullptr;
+    size_t size = 0;
+    if (hipMemGetAddressRange(&base, &size, const_cast<void*>(p)) == hipSuccess) {
+        const uint8_t* lo = static_cast<const uint8_t*>(base);
+        return b >= lo && b + bytes <= lo + size;
+    }
+    (void)hipGetLastError();       // no range for this kind of pointer: the two end bytes decide
+    return true;
 }
 
 struct StageBuf {
@@ -637,7 +675,7 @@ int stream_op(StreamEngine& e, size_t n, size_t chunk, const std::vector<Span>& 
     const size_t nchunks = (n + chunk - 1) / chunk;
     const int nsets = nchunks < (size_t)NSETS ? (int)nchunks : NSETS;
     std::vector<char> staged(spans.size());
-    for (size_t j = 0; j < spans.size(); j++) staged[j] = !host_pinned(spans[j].in ? spans[j].in : spans[j].out);
+    for (size_t j = 0; j < spans.size(); j++) staged[j] = !host_pinned(spans[j].in ? spans[j].in : spans[j].out, n * spans[j].bytes);
     int rc = engine_prepare(e, dev, chunk, spans, staged, nsets);
     auto drain = [&](BufSet& s) -> int {   // wait for the set's D2H copies and hand staged outputs to the caller
         if (!s.pending) return MLKEM_OK;
@@ -691,26 +729,51 @@ int stream_op(StreamEngine& e, size_t n, size_t chunk, const std::vector<Span>& 
     return rc;
 }
 
+// Ownership: the registry and every call in flight hold a shared_ptr.  mlkem_host_release() takes the entries out of the
+// registry, wipes and frees their contents under the entry's own locks (so it waits for calls in flight) and drops its
+// reference; a call that had already looked its entry up keeps the object alive, finds it empty, rebuilds what it needs in
+// the orphaned entry, and the destructor wipes and frees that when the call returns.  Release is therefore safe to call
+// from any thread at any time.
 struct HostState {
     std::mutex mu;              // serialises the host-pointer primitives of one device
     int device = 0;
     mlkem_ctx* ctx = nullptr;   // chunk capacity 1: the primitives use no scratch
     StreamEngine eng;
+    void wipe() {               // zero + free everything cached; the entry stays usable (contents are rebuilt on demand)
+        {
+            std::lock_guard<std::mutex> l2(eng.mu);
+            engine_release(eng);
+        }
+        std::lock_guard<std::mutex> l3(mu);
+        if (ctx) mlkem_ctx_destroy(ctx);
+        ctx = nullptr;
+    }
+    ~HostState() { wipe(); }
 };
+using HostRef = std::shared_ptr<HostState>;
 std::mutex g_reg_mu;
-std::map<int, HostState*> g_host;
+// leaked on purpose: a static map would run ~HostState (HIP calls) during static destruction, after the runtime is gone
+std::map<int, HostRef>& g_host = *new std::map<int, HostRef>();
 
-HostState* host_state_current(int* dev_out = nullptr) {
+HostRef host_state_current(int* dev_out = nullptr) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return nullptr;
     if (dev_out) *dev_out = dev;
     std::lock_guard<std::mutex> lock(g_reg_mu);
-    HostState*& hs = g_host[dev];
+    HostRef& hs = g_host[dev];
     if (!hs) {
-        hs = new (std::nothrow) HostState();
+        hs.reset(new (std::nothrow) HostState());
         if (hs) hs->device = dev;
     }
     return hs;
+}
+std::vector<HostRef> host_state_snapshot(bool take) {   // take: the registry forgets them
+    std::lock_guard<std::mutex> lock(g_reg_mu);
+    std::vector<HostRef> v;
+    for (auto& kv : g_host)
+        if (kv.second) v.push_back(kv.second);
+    if (take) g_host.clear();
+    return v;
 }
 // caller holds hs->mu
 int host_ctx(HostState* hs, mlkem_ctx** out) {
@@ -720,6 +783,19 @@ int host_ctx(HostState* hs, mlkem_ctx** out) {
     }
     *out = hs->ctx;
     return MLKEM_OK;
+}
+
+// No C++ exception may cross the C boundary: allocation failures inside the host paths (staging threads, vectors) come back
+// as MLKEM_ERR_ALLOC.
+template <class Fn>
+int guarded(Fn fn) {
+    try {
+        return fn();
+    } catch (const std::bad_alloc&) {
+        return MLKEM_ERR_ALLOC;
+    } catch (...) {   // std::system_error from std::thread / std::mutex: resources exhausted
+        return MLKEM_ERR_ALLOC;
+    }
 }
 
 // the three KEM operations as (spans, launch) pairs for stream_op
@@ -747,9 +823,11 @@ int kem_stream(StreamEngine& e, int op, int set, size_t n, const void* a, const 
 }
 
 int kem_stream_current(int op, int set, size_t n, const void* a, const void* b, void* x, void* y, size_t chunk) {
-    HostState* hs = host_state_current();
-    if (!hs) return MLKEM_ERR_NO_DEVICE;
-    return kem_stream(hs->eng, op, set, n, a, b, x, y, chunk);
+    return guarded([&]() -> int {
+        HostRef hs = host_state_current();
+        if (!hs) return MLKEM_ERR_NO_DEVICE;
+        return kem_stream(hs->eng, op, set, n, a, b, x, y, chunk);
+    });
 }
 
 }   // namespace
@@ -766,8 +844,10 @@ int mlkem_encaps(int set, size_t n, const uint8_t* ek, const uint8_t* m, uint8_t
 }
 int mlkem_decaps(int set, size_t n, const uint8_t* dk, const uint8_t* c, uint8_t* K, int32_t* status) {
     if (status || n == 0) return mlkem_decaps_stream(set, n, dk, c, K, status, 0);
-    std::vector<int32_t> st(n);   // the caller did not ask for the hash-check codes; K does not depend on them
-    return mlkem_decaps_stream(set, n, dk, c, K, st.data(), 0);
+    return guarded([&]() -> int {
+        std::vector<int32_t> st(n);   // the caller did not ask for the hash-check codes; K does not depend on them
+        return mlkem_decaps_stream(set, n, dk, c, K, st.data(), 0);
+    });
 }
 int mlkem_keygen_stream(int set, size_t n, const uint8_t* d, const uint8_t* z, uint8_t* ek, uint8_t* dk, size_t chunk_items) {
     return kem_stream_current(0, set, n, d, z, ek, dk, chunk_items);
@@ -790,38 +870,24 @@ int mlkem_host_unregister(void* p) {
 }
 
 void mlkem_stream_release(void) {
-    std::lock_guard<std::mutex> lock(g_reg_mu);
-    for (auto& kv : g_host) {
-        std::lock_guard<std::mutex> l2(kv.second->eng.mu);
-        engine_release(kv.second->eng);
+    for (HostRef& hs : host_state_snapshot(false)) {
+        std::lock_guard<std::mutex> l2(hs->eng.mu);
+        engine_release(hs->eng);
     }
 }
-// wipes and frees everything the host-pointer entry points cached, on every device they were used on
+// wipes and frees everything the host-pointer entry points cached, on every device they were used on; safe against calls
+// in flight on other threads (see HostState)
 void mlkem_host_release(void) {
-    std::lock_guard<std::mutex> lock(g_reg_mu);
-    for (auto& kv : g_host) {
-        HostState* hs = kv.second;
-        {
-            std::lock_guard<std::mutex> l2(hs->eng.mu);
-            engine_release(hs->eng);
-        }
-        {
-            std::lock_guard<std::mutex> l3(hs->mu);
-            if (hs->ctx) mlkem_ctx_destroy(hs->ctx);
-            hs->ctx = nullptr;
-        }
-        delete hs;
-    }
-    g_host.clear();
+    for (HostRef& hs : host_state_snapshot(true)) hs->wipe();
 }
 
 // ---- host-pointer primitives ----------------------------------------------------------------------------------
 #define MLKEM_HOST_PROLOGUE()                                   \
-    HostState* hs = host_state_current();                       \
+    HostRef hs = host_state_current();                          \
     if (!hs) return MLKEM_ERR_NO_DEVICE;                        \
     std::lock_guard<std::mutex> lock(hs->mu);                   \
     mlkem_ctx* ctx;                                             \
-    int rc = host_ctx(hs, &ctx);                                \
+    int rc = host_ctx(hs.get(), &ctx);                          \
     if (rc) return rc;
 
 static int host_ntt(bool inverse, size_t n, const uint16_t* in, uint16_t* out) {
@@ -863,7 +929,7 @@ int mlkem_sample_cbd(int eta, size_t n, const uint8_t* bytes, uint16_t* f) {
     return MLKEM_OK;
 }
 
-int mlkem_keccak_sponge(unsigned rate, size_t n, const uint8_t* padded, unsigned nblocks, uint8_t* out, unsigned outlen) {
+static int host_keccak_sponge(unsigned rate, size_t n, const uint8_t* padded, unsigned nblocks, uint8_t* out, unsigned outlen) {
     if (n && (!padded || !out)) return MLKEM_ERR_ARG;
     MLKEM_HOST_PROLOGUE()
     if (n == 0) return MLKEM_OK;
@@ -877,6 +943,9 @@ int mlkem_keccak_sponge(unsigned rate, size_t n, const uint8_t* padded, unsigned
     HIP_TRY(hipMemcpy(tmp.data(), bo.p, n * ostride, hipMemcpyDeviceToHost));
     for (size_t i = 0; i < n; i++) memcpy(out + i * outlen, tmp.data() + i * ostride, outlen);
     return MLKEM_OK;
+}
+int mlkem_keccak_sponge(unsigned rate, size_t n, const uint8_t* padded, unsigned nblocks, uint8_t* out, unsigned outlen) {
+    return guarded([&]() -> int { return host_keccak_sponge(rate, n, padded, nblocks, out, outlen); });
 }
 // Compress_d / Decompress_d for any d in 1..12 (ml_kem.c:83-119; d = 12 is the identity there) over n values
 int mlkem_compress(int d, size_t n, const uint16_t* x, uint16_t* y) {
@@ -916,23 +985,27 @@ static bool fill_random(uint8_t* p, size_t n) {
 int mlkem_keygen_random(int set, size_t n, uint8_t* ek, uint8_t* dk) {
     ParamSet p;
     if (!param_set(set, p)) return MLKEM_ERR_PARAM_SET;
-    std::vector<uint8_t> d(n * 32 + 1), z(n * 32 + 1);
-    int rc = MLKEM_ERR_RNG;
-    if (fill_random(d.data(), n * 32) && fill_random(z.data(), n * 32)) rc = mlkem_keygen(set, n, d.data(), z.data(), ek, dk);
-    explicit_bzero(d.data(), d.size());
-    explicit_bzero(z.data(), z.size());
-    return rc;
+    return guarded([&]() -> int {
+        std::vector<uint8_t> d(n * 32 + 1), z(n * 32 + 1);
+        int rc = MLKEM_ERR_RNG;
+        if (fill_random(d.data(), n * 32) && fill_random(z.data(), n * 32)) rc = mlkem_keygen(set, n, d.data(), z.data(), ek, dk);
+        explicit_bzero(d.data(), d.size());
+        explicit_bzero(z.data(), z.size());
+        return rc;
+    });
 }
 
 int mlkem_encaps_random(int set, size_t n, const uint8_t* ek, unsigned ek_len, uint8_t* c, uint8_t* K) {
     ParamSet p;
     if (!param_set(set, p)) return MLKEM_ERR_PARAM_SET;
     if (ek_len != p.ek_len) return MLKEM_ERR_LENGTH;   // ml_kem.c:1267-1271; the modulus check that follows is a no-op (F3)
-    std::vector<uint8_t> m(n * 32 + 1);
-    int rc = MLKEM_ERR_RNG;
-    if (fill_random(m.data(), n * 32)) rc = mlkem_encaps(set, n, ek, m.data(), c, K);
-    explicit_bzero(m.data(), m.size());
-    return rc;
+    return guarded([&]() -> int {
+        std::vector<uint8_t> m(n * 32 + 1);
+        int rc = MLKEM_ERR_RNG;
+        if (fill_random(m.data(), n * 32)) rc = mlkem_encaps(set, n, ek, m.data(), c, K);
+        explicit_bzero(m.data(), m.size());
+        return rc;
+    });
 }
 
 }   // extern "C"
@@ -945,15 +1018,69 @@ int mlkem_encaps_random(int set, size_t n, const uint8_t* ek, unsigned ek_len, u
 //                events, pinned staging) on its device; the call returns when every member has finished
 //   *_multi_dev  device-resident shards: shard r already lives on member r's device; the work is enqueued on the member's
 //                stream and the call returns without synchronising (mlkem_multi_sync waits for all members)
+// One persistent host thread per member: started on the member's first host-resident call, bound to the member's device
+// once, fed one job at a time through a mutex + condition variable, joined by mlkem_multi_destroy.  (A std::thread per
+// call cost a thread creation + hipSetDevice per member and call.)
+struct MemberWorker {
+    std::mutex mu;
+    std::condition_variable cv;
+    std::function<void()> job;
+    bool has_job = false, done = false, quit = false;
+    std::thread th;
+    void loop(int device) {
+        const bool dev_ok = hipSetDevice(device) == hipSuccess;
+        std::unique_lock<std::mutex> lk(mu);
+        for (;;) {
+            cv.wait(lk, [&] { return has_job || quit; });
+            if (quit) return;
+            std::function<void()> j = std::move(job);
+            has_job = false;
+            lk.unlock();
+            if (dev_ok) j();
+            lk.lock();
+            job_ok = dev_ok;
+            done = true;
+            cv.notify_all();
+        }
+    }
+    bool job_ok = true;   // false: the worker could not select its device and did not run the job
+    void start(int device) {
+        if (!th.joinable()) th = std::thread([this, device] { loop(device); });
+    }
+    void post(std::function<void()> j) {
+        std::lock_guard<std::mutex> lk(mu);
+        job = std::move(j);
+        has_job = true;
+        done = false;
+        cv.notify_all();
+    }
+    bool wait() {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return done; });
+        return job_ok;
+    }
+    void stop() {
+        if (!th.joinable()) return;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            quit = true;
+            cv.notify_all();
+        }
+        th.join();
+    }
+};
+
 struct mlkem_multi {
     struct Member {
         int device = 0;
         mlkem_ctx* ctx = nullptr;       // *_multi_dev: created on first use (a context owns ~10 KiB x chunk of HBM)
         hipStream_t st = nullptr;
         StreamEngine eng;               // *_multi
+        MemberWorker worker;            // *_multi: members 1 .. R-1 (member 0 runs on the calling thread)
     };
     std::vector<Member*> mem;
     size_t chunk = 0;
+    std::mutex call_mu;                 // one host-resident call at a time per mlkem_multi (the workers take one job each)
 };
 
 namespace {
@@ -964,28 +1091,37 @@ int member_ready(mlkem_multi* mm, mlkem_multi::Member& m) {   // m.device is cur
     return MLKEM_OK;
 }
 
-// one host thread per member; fn(member index) runs with the member's device current
+// fn(member index) runs with the member's device current: member 0 on the calling thread, the others on their workers
 template <class Fn>
 int multi_run_threads(mlkem_multi* mm, Fn fn) {
     const size_t R = mm->mem.size();
+    std::lock_guard<std::mutex> call_lock(mm->call_mu);
     std::vector<int> rcs(R, MLKEM_OK);
     std::vector<std::string> errs(R);
-    auto body = [&](size_t r) {
-        if (hipSetDevice(mm->mem[r]->device) != hipSuccess) { rcs[r] = MLKEM_ERR_NO_DEVICE; return; }
-        rcs[r] = fn(r);
-        if (rcs[r]) errs[r] = g_last_hip_error;
-    };
-    std::vector<std::thread> th;
-    for (size_t r = 1; r < R; r++) th.emplace_back(body, r);
-    {
+    // the jobs reference this frame: whatever fails below, every posted job is waited for before the frame is left
+    size_t posted = 1;
+    int post_rc = MLKEM_OK;
+    try {
+        for (size_t r = 1; r < R; r++) mm->mem[r]->worker.start(mm->mem[r]->device);
+        for (size_t r = 1; r < R; r++, posted++)
+            mm->mem[r]->worker.post([&, r] {
+                rcs[r] = guarded([&]() -> int { return fn(r); });
+                if (rcs[r]) errs[r] = g_last_hip_error;
+            });
+    } catch (...) {
+        post_rc = MLKEM_ERR_ALLOC;
+    }
+    if (post_rc == MLKEM_OK) {
         DeviceGuard g;
         if (!g.enter(mm->mem[0]->device)) rcs[0] = MLKEM_ERR_NO_DEVICE;
         else {
-            rcs[0] = fn(0);
+            rcs[0] = guarded([&]() -> int { return fn(0); });
             if (rcs[0]) errs[0] = g_last_hip_error;
         }
     }
-    for (auto& t : th) t.join();
+    for (size_t r = 1; r < posted; r++)
+        if (!mm->mem[r]->worker.wait() && rcs[r] == MLKEM_OK) rcs[r] = MLKEM_ERR_NO_DEVICE;
+    if (post_rc != MLKEM_OK) return post_rc;
     for (size_t r = 0; r < R; r++)
         if (rcs[r]) {
             g_last_hip_error = errs[r];
@@ -1034,6 +1170,7 @@ void mlkem_multi_destroy(mlkem_multi* mm) {
     if (!mm) return;
     DeviceGuard g;
     for (auto* m : mm->mem) {
+        m->worker.stop();
         (void)g.enter(m->device);
         if (m->st) (void)hipStreamSynchronize(m->st);
         if (m->ctx) mlkem_ctx_destroy(m->ctx);
@@ -1059,10 +1196,12 @@ static int multi_host(mlkem_multi* mm, int op, int set, size_t n, const uint8_t*
     const size_t la = op == 0 ? 32 : op == 1 ? p.ek_len : p.dk_len, lb = op == 2 ? p.c_len : 32;
     const size_t lx = op == 0 ? p.ek_len : op == 1 ? p.c_len : 32, ly = op == 0 ? p.dk_len : op == 1 ? 32 : 4;
     const int R = (int)mm->mem.size();
-    return multi_run_threads(mm, [&](size_t r) -> int {
-        size_t lo, hi;
-        mlkem_shard_range(n, (int)r, R, &lo, &hi);
-        return kem_stream(mm->mem[r]->eng, op, set, hi - lo, a + lo * la, b + lo * lb, x + lo * lx, y + lo * ly, chunk_items);
+    return guarded([&]() -> int {
+        return multi_run_threads(mm, [&](size_t r) -> int {
+            size_t lo, hi;
+            mlkem_shard_range(n, (int)r, R, &lo, &hi);
+            return kem_stream(mm->mem[r]->eng, op, set, hi - lo, a + lo * la, b + lo * lb, x + lo * lx, y + lo * ly, chunk_items);
+        });
     });
 }
 int mlkem_keygen_multi(mlkem_multi* mm, int set, size_t n, const uint8_t* d, const uint8_t* z, uint8_t* ek, uint8_t* dk, size_t chunk_items) {
@@ -1073,8 +1212,10 @@ int mlkem_encaps_multi(mlkem_multi* mm, int set, size_t n, const uint8_t* ek, co
 }
 int mlkem_decaps_multi(mlkem_multi* mm, int set, size_t n, const uint8_t* dk, const uint8_t* c, uint8_t* K, int32_t* status, size_t chunk_items) {
     if (status || n == 0) return multi_host(mm, 2, set, n, dk, c, K, reinterpret_cast<uint8_t*>(status), chunk_items);
-    std::vector<int32_t> st(n);
-    return multi_host(mm, 2, set, n, dk, c, K, reinterpret_cast<uint8_t*>(st.data()), chunk_items);
+    return guarded([&]() -> int {
+        std::vector<int32_t> st(n);
+        return multi_host(mm, 2, set, n, dk, c, K, reinterpret_cast<uint8_t*>(st.data()), chunk_items);
+    });
 }
 
 // ---- device-resident shards ------------------------------------------------------------------------------------------
@@ -1110,6 +1251,16 @@ int mlkem_encaps_multi_dev(mlkem_multi* mm, int set, const size_t* n_shard, cons
 int mlkem_decaps_multi_dev(mlkem_multi* mm, int set, const size_t* n_shard, const uint8_t* const* dk, const uint8_t* const* c,
                            uint8_t* const* K, int32_t* const* status) {
     return multi_dev(mm, 2, set, n_shard, dk, c, K, reinterpret_cast<void* const*>(status));
+}
+// the HIP stream member `member` enqueues its device-resident work on (created on first use): lets a caller order that
+// stream after the producers of its inputs (hipStreamWaitEvent) and time or consume the member's work with events
+void* mlkem_multi_stream(mlkem_multi* mm, int member) {
+    if (!mm || member < 0 || member >= (int)mm->mem.size()) return nullptr;
+    auto& m = *mm->mem[member];
+    DeviceGuard g;
+    if (!g.enter(m.device)) return nullptr;
+    if (!m.st && !hip_ok(hipStreamCreateWithFlags(&m.st, hipStreamNonBlocking), "hipStreamCreate")) return nullptr;
+    return m.st;
 }
 int mlkem_multi_sync(mlkem_multi* mm) {
     if (!mm) return MLKEM_ERR_ARG;

@@ -35,6 +35,7 @@ using stream_t = hipStream_t;
 struct LaunchRecorder {
     struct Rec { const char* label; hipEvent_t a, b; };
     std::vector<Rec> recs;
+    bool failed = false;   // an event could not be created / recorded: the rows would be incomplete
 };
 inline LaunchRecorder*& launch_recorder() {
     static thread_local LaunchRecorder* r = nullptr;
@@ -50,16 +51,18 @@ inline void launch(const char* label, void (*kfn)(KArgs...), size_t grid, unsign
     emu::launch((unsigned)grid, block, [=] { kfn(args...); });
 #else
     LaunchRecorder* rec = launch_recorder();
-    if (rec) {
-        LaunchRecorder::Rec r{label, nullptr, nullptr};
-        (void)hipEventCreate(&r.a);
-        (void)hipEventCreate(&r.b);
-        (void)hipEventRecord(r.a, st);
-        kfn<<<dim3((unsigned)grid), dim3(block), 0, st>>>(args...);
-        (void)hipEventRecord(r.b, st);
+    LaunchRecorder::Rec r{label, nullptr, nullptr};
+    // the kernel is launched whatever happens to the measurement: an event that cannot be created or recorded drops this
+    // launch from the timing and marks the recorder failed (mlkem_timing_end reports it instead of a silent zero)
+    bool timed = rec && hipEventCreate(&r.a) == hipSuccess && hipEventCreate(&r.b) == hipSuccess && hipEventRecord(r.a, st) == hipSuccess;
+    kfn<<<dim3((unsigned)grid), dim3(block), 0, st>>>(args...);
+    if (timed) timed = hipEventRecord(r.b, st) == hipSuccess;
+    if (timed) {
         rec->recs.push_back(r);
-    } else {
-        kfn<<<dim3((unsigned)grid), dim3(block), 0, st>>>(args...);
+    } else if (rec) {
+        rec->failed = true;
+        if (r.a) (void)hipEventDestroy(r.a);
+        if (r.b) (void)hipEventDestroy(r.b);
     }
 #endif
 }
@@ -489,6 +492,18 @@ inline void ntt_launch(stream_t st, bool inverse, size_t n, const uint16_t* in, 
 }
 inline void basemul_launch(stream_t st, size_t n, const uint16_t* a, const uint16_t* b, uint16_t* h) {
     launch("k_basemul_batch", k_basemul_batch, poly_grid(n), WAVE * ARITH_WAVES, st, n, a, b, h);
+}
+// VectorMultiply over n items of k polynomial pairs each; PolyAddition / PolySubtraction over n_values coefficients
+inline int vecmul_launch(stream_t st, int k, size_t n, const uint16_t* u, const uint16_t* v, uint16_t* w) {
+    if (k < 1 || k > 4) return -1;
+    launch("k_vecmul_batch", k_vecmul_batch, poly_grid(n), WAVE * ARITH_WAVES, st, n, k, u, v, w);
+    return 0;
+}
+inline void poly_addsub_launch(stream_t st, bool sub, size_t n_values, const uint16_t* a, const uint16_t* b, uint16_t* out) {
+    size_t grid = ceil_div(ceil_div(n_values, 8), 256);
+    if (grid > 256 * 8) grid = 256 * 8;
+    if (sub) launch("k_poly_sub", k_poly_addsub<true>, grid, 256u, st, n_values, a, b, out);
+    else launch("k_poly_add", k_poly_addsub<false>, grid, 256u, st, n_values, a, b, out);
 }
 inline int cbd_launch(stream_t st, int eta, size_t n, const uint8_t* bytes, uint16_t* out) {
     if (eta == 2) launch("k_cbd_batch", k_cbd_batch<2>, poly_grid(n), WAVE * ARITH_WAVES, st, n, bytes, out);

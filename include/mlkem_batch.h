@@ -73,7 +73,8 @@ int mlkem_ctx_set_conformance(mlkem_ctx* ctx, int mode);
 /* ---- per-kernel timing (measurement aid used by bench.py) ---------------------------------------------
  * Between begin and end, every kernel launched by this thread is bracketed by HIP events on its launch
  * stream.  mlkem_timing_end synchronises and returns per-kernel-label rows: labels[32*i..] (NUL-terminated),
- * total_ms[i], counts[i]; return value = number of rows (<= max) or a negative error. */
+ * total_ms[i], counts[i]; return value = number of rows (<= max) or a negative error (MLKEM_ERR_NO_DEVICE when an event
+ * could not be created or recorded: incomplete rows are not reported). */
 int mlkem_timing_begin(void);
 int mlkem_timing_end(char* labels, double* total_ms, int* counts, int max);
 
@@ -131,6 +132,14 @@ int mlkem_ntt_dev(mlkem_ctx* ctx, size_t n, const uint16_t* f, uint16_t* f_hat, 
 int mlkem_intt_dev(mlkem_ctx* ctx, size_t n, const uint16_t* f_hat, uint16_t* f, void* stream);
 /* replaces MultiplyNTTs(f, g)  ml_kem.c:415-442 ; inputs may be any 12-bit value (as ByteDecode_12 yields) */
 int mlkem_multiply_ntts_dev(mlkem_ctx* ctx, size_t n, const uint16_t* f_hat, const uint16_t* g_hat, uint16_t* h_hat, void* stream);
+/* replaces VectorMultiply(u, v, k) ml_kem.c:618-638 ; u, v : n x k x uint16[256] (k = 1..4, any 12-bit values),
+ * w : n x uint16[256] = sum_i MultiplyNTTs(u[i], v[i]), every partial sum reduced as PolyAddition does */
+int mlkem_vector_multiply_dev(mlkem_ctx* ctx, int k, size_t n, const uint16_t* u, const uint16_t* v, uint16_t* w, void* stream);
+/* replaces PolyAddition(u, v) / PolySubtraction(u, v)  ml_kem.c:580-592 / :599-613, coefficient by coefficient over n_values
+ * uint16 values (256 per polynomial), inputs taken mod 2^12 like the reference's `union integer.t`:
+ *   add: (u + v) % q ;  sub: u < v ? q - (v - u) : u - v, stored into the reference's 12-bit field.  In-place allowed. */
+int mlkem_poly_add_dev(mlkem_ctx* ctx, size_t n_values, const uint16_t* u, const uint16_t* v, uint16_t* z, void* stream);
+int mlkem_poly_sub_dev(mlkem_ctx* ctx, size_t n_values, const uint16_t* u, const uint16_t* v, uint16_t* z, void* stream);
 /* replaces ByteEncode(Compress(f, d), d)   ml_kem.c:83-97 + :125-145 ; f : n x uint16[256] -> bytes : n x 32d ;
  *          d in {1, 4, 5, 10, 11} (coefficients taken mod 2^12, then mod q) ; d = 12 : ByteEncode_12 alone (ml_kem.c:736-756) */
 int mlkem_compress_encode_dev(mlkem_ctx* ctx, int d, size_t n, const uint16_t* f, uint8_t* bytes, void* stream);
@@ -192,8 +201,9 @@ int mlkem_compress(int d, size_t n, const uint16_t* x, uint16_t* y);
 int mlkem_decompress(int d, size_t n, const uint16_t* y, uint16_t* x);
 /* All state the host-pointer calls cache is kept PER DEVICE (the HIP device current in the calling thread): threads that
  * work on different devices share nothing.  mlkem_host_release() zeroes and frees all of it (contexts, streams, pinned and
- * device staging) on every device; mlkem_stream_release() only the streaming engines.  Neither may run while another
- * thread is inside a host-pointer call (they free what that call is using). */
+ * device staging) on every device; mlkem_stream_release() only the streaming engines.  Both may be called from any thread
+ * at any time: the cached state is reference-counted, a release waits for calls in flight on the same device's locks, and
+ * a call that overlaps a release simply rebuilds (and afterwards frees) what it needs. */
 void mlkem_host_release(void);
 
 /* ---- layout converters and streaming front-end --------------------------------------------------
@@ -201,7 +211,7 @@ void mlkem_host_release(void);
  * undefined).  Device-side converters at memory bandwidth: */
 int mlkem_cells_to_bytes_dev(mlkem_ctx* ctx, size_t n_cells, const uint32_t* cells, uint8_t* bytes, void* stream);
 int mlkem_bytes_to_cells_dev(mlkem_ctx* ctx, size_t n_cells, const uint8_t* bytes, uint32_t* cells, void* stream);
-/* Host-resident batches of any size in chunks (chunk_items = 0 -> 2^14, env MLKEM_STREAM_CHUNK_ITEMS): three streams
+/* Host-resident batches of any size in chunks (chunk_items = 0 -> 2^15, env MLKEM_STREAM_CHUNK_ITEMS): three streams
  * (H2D / kernels / D2H) and three buffer sets ordered by events, so that H2D(i+1), kernels(i) and D2H(i-1) overlap (PCIe is
  * full duplex).  Caller buffers that are pinned (hipHostMalloc, hipHostRegister or mlkem_host_register below) are handed to
  * the DMA engines directly; pageable buffers go through pinned staging with threaded copies.  Same results as the
@@ -248,6 +258,10 @@ int mlkem_encaps_multi_dev(mlkem_multi* mm, int param_set, const size_t* n_shard
 int mlkem_decaps_multi_dev(mlkem_multi* mm, int param_set, const size_t* n_shard, const uint8_t* const* dk, const uint8_t* const* c,
                            uint8_t* const* K, int32_t* const* status);
 int mlkem_multi_sync(mlkem_multi* mm);
+/* The hipStream_t (as void*) member `member` enqueues its device-resident work on; created on first use, owned by the
+ * mlkem_multi.  A caller orders it after the producers of its inputs (hipStreamWaitEvent on it) and times or consumes the
+ * member's work with events recorded on it.  NULL on a bad argument. */
+void* mlkem_multi_stream(mlkem_multi* mm, int member);
 
 /* ---- randomised wrappers: seeds drawn on the host with getrandom(2) ---------------- */
 /* replaces KEM_KeyGen(params)  ml_kem.c:1233-1252 for n key pairs */

@@ -278,6 +278,9 @@ class Ref:
         L.ref_bitrev7.restype = C.c_uint
         L.ref_time_encaps_decaps.restype = C.c_double
         L.ref_time_encaps_decaps.argtypes = [C.c_int, C.c_int, u8p, u8p, u8p, u8p, u8p, C.POINTER(C.c_int)]
+        if hasattr(L, "ref_time_triples"):   # absent from an oracle/_ref built by an earlier round
+            L.ref_time_triples.restype = C.c_double
+            L.ref_time_triples.argtypes = [C.c_int, C.c_int, u8p, u8p, u8p, u8p, u8p, u8p, u8p, C.POINTER(C.c_int)]
 
     def keygen(self, pset, d, z):
         ekl, dkl, _ = SIZES[pset]
@@ -470,3 +473,15 @@ class Ref:
         agree = C.c_int(0)
         secs = self.lib.ref_time_encaps_decaps(pset, n, _p8(ek), _p8(dk), _p8(m), _p8(c), _p8(K), C.byref(agree))
         return secs, c, K, agree.value
+
+    def time_triples(self, pset, d, z, m):
+        """KeyGen_internal + Encaps_internal + KEM_Decaps over the given seed sets on ONE core; returns
+        (seconds, ek, dk, c, K, items_that_agree)."""
+        ekl, dkl, cl = SIZES[pset]
+        d, z, m = (_u8(x).reshape(-1, 32) for x in (d, z, m))
+        n = m.shape[0]
+        ek, dk = np.zeros((n, ekl), np.uint8), np.zeros((n, dkl), np.uint8)
+        c, K = np.zeros((n, cl), np.uint8), np.zeros((n, 32), np.uint8)
+        agree = C.c_int(0)
+        secs = self.lib.ref_time_triples(pset, n, _p8(d), _p8(z), _p8(m), _p8(ek), _p8(dk), _p8(c), _p8(K), C.byref(agree))
+        return secs, ek, dk, c, K, agree.value

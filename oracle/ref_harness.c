@@ -293,3 +293,25 @@ double ref_time_encaps_decaps(int set, int pairs, const uint8_t *ek, const uint8
     *agree = ok;
     return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
 }
+
+/* KeyGen_internal + Encaps_internal + KEM_Decaps on `n` seed sets (BASELINE configs[3] as a CPU leg); returns elapsed
+ * seconds, the keys / ciphertexts / shared secrets, and the number of items whose two shared secrets agree. */
+double ref_time_triples(int set, int n, const uint8_t *d, const uint8_t *z, const uint8_t *m, uint8_t *ek_out,
+                        uint8_t *dk_out, uint8_t *c_out, uint8_t *K_out, int *agree) {
+    unsigned ek_len, dk_len, c_len;
+    ref_sizes(set, &ek_len, &dk_len, &c_len);
+    struct timespec t0, t1;
+    int ok = 0;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (int i = 0; i < n; i++) {
+        uint8_t K2[32];
+        uint8_t *ek = ek_out + (size_t)i * ek_len, *dk = dk_out + (size_t)i * dk_len, *c = c_out + (size_t)i * c_len;
+        ref_keygen(set, d + 32 * (size_t)i, z + 32 * (size_t)i, ek, dk);
+        ref_encaps(set, ek, m + 32 * (size_t)i, c, K_out + 32 * (size_t)i);
+        int rc = ref_kem_decaps(set, dk, dk_len, c, c_len, K2);
+        if (rc == 0 && memcmp(K2, K_out + 32 * (size_t)i, 32) == 0) ok++;
+    }
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    *agree = ok;
+    return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+}

@@ -107,6 +107,8 @@ int emu_codec(int encode, int d, size_t n, const void* in, void* out) { return c
 void emu_ntt(int inverse, size_t n, const uint16_t* in, uint16_t* out) { ntt_launch(nullptr, inverse != 0, n, in, out); }
 void emu_basemul(size_t n, const uint16_t* a, const uint16_t* b, uint16_t* h) { basemul_launch(nullptr, n, a, b, h); }
 int emu_cbd(int eta, size_t n, const uint8_t* bytes, uint16_t* out) { return cbd_launch(nullptr, eta, n, bytes, out); }
+int emu_vecmul(int k, size_t n, const uint16_t* u, const uint16_t* v, uint16_t* w) { return vecmul_launch(nullptr, k, n, u, v, w); }
+void emu_poly_addsub(int sub, size_t n_values, const uint16_t* a, const uint16_t* b, uint16_t* out) { poly_addsub_launch(nullptr, sub != 0, n_values, a, b, out); }
 void emu_sample_ntt(size_t n, const uint8_t* seeds, uint16_t* out) { sample_ntt_launch(nullptr, n, seeds, out); }
 int emu_prf(int eta, size_t n, const uint8_t* in33, uint8_t* out) { return prf_launch(nullptr, eta, n, in33, out); }
 int emu_hash(int kind, size_t n, const uint8_t* msg, unsigned len, size_t stride, uint8_t* out) {

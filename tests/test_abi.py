@@ -224,3 +224,40 @@ print("rng-failure OK")
     r = subprocess.run([sys.executable, "-c", child, pkg.SHIM_PATH], capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0 and "rng-failure OK" in r.stdout, (r.stdout[-1000:], r.stderr[-2000:])
     assert "Random bit generation failed" in r.stderr   # the reference's message (ERR_MSG, ml_kem.c:11-13)
+
+
+def test_release_while_other_threads_call_is_safe_without_gpu(pkg):
+    """Two threads inside host-pointer calls while a third keeps releasing the cached host state: no crash, and without a
+    device every call still fails loudly.  (The same race on a real device, where the registry holds engines and contexts,
+    is tests/test_gpu_round3.py::test_host_release_races_with_calls_in_flight.)"""
+    import threading
+    import numpy as np
+    lib = pkg.load_library()
+    if lib.mlkem_device_count() > 0:
+        pytest.skip("covered by the GPU tier on a box with a device")
+    stop = threading.Event()
+    rcs = []
+
+    def caller():
+        f = np.zeros((4, 256), np.uint16)
+        d = np.zeros((4, 32), np.uint8)
+        ek, dk = np.zeros((4, 1184), np.uint8), np.zeros((4, 2400), np.uint8)
+        for _ in range(300):
+            rcs.append(lib.mlkem_ntt(4, f.ctypes.data, f.ctypes.data))
+            rcs.append(lib.mlkem_keygen(768, 4, d.ctypes.data, d.ctypes.data, ek.ctypes.data, dk.ctypes.data))
+
+    def releaser():
+        while not stop.is_set():
+            lib.mlkem_host_release()
+            lib.mlkem_stream_release()
+
+    ts = [threading.Thread(target=caller) for _ in range(2)]
+    rel = threading.Thread(target=releaser)
+    rel.start()
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    stop.set()
+    rel.join()
+    assert len(rcs) == 1200 and set(rcs) == {-100}

@@ -1,6 +1,7 @@
 """The N > 1 path (contiguous shards, no data-path collective).
 
-CPU tier  world_size-2 gloo: shard_range, the global-index seeding and bench.py's barrier / max-over-ranks plumbing; the
+CPU tier  world_size-2 gloo: shard_range, the global-index seeding and bench.py's barrier / max-over-ranks / all-ranks-ok /
+          per-rank gather plumbing; the
           per-shard compute is the oracle there (the HIP engine cannot run without a GPU), i.e. the checker stands in.
 GPU tier  the same two-rank job with every shard computed by the HIP ENGINE (both ranks on device 0, gloo for the barrier,
           as bench.py's rehearsal mode does) against the single-context bytes and the oracle."""
@@ -65,6 +66,12 @@ def _worker(rank, world, port, n, out_dir, use_engine):
     bench.barrier(world)
     t = bench.max_over_ranks(float(rank + 1), world, torch.device("cuda", 0) if use_engine else torch.device("cpu"))
     assert t == float(world)
+    # bench.py's gate is the AND over ALL ranks, and every rank learns it (a wrong byte on rank 1 must fail the job)
+    dv = torch.device("cuda", 0) if use_engine else torch.device("cpu")
+    assert bench.all_ranks_ok(True, dv) is True
+    assert bench.all_ranks_ok(rank != world - 1, dv) is False
+    per = bench.gather_per_gpu({"rank": rank, "value": 10.0 * (rank + 1)})
+    assert [p["rank"] for p in per] == list(range(world)) and per[-1]["value"] == 10.0 * world
     # gather per-item digests on rank 0 (test-only collective; the product's data path has none)
     gathered = [None] * world
     dist.all_gather_object(gathered, (lo, hi, _digests(c, K).tobytes()))

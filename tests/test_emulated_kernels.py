@@ -387,3 +387,45 @@ def test_emu_register_ntt_four_polys_per_wave(emu, oracle, golden_npz):
         emu.emu_ntt(1, C.c_size_t(a.shape[0]), p16(a), p16(out))
         assert (out == want_i).all(), a.shape
     assert want_f[1, 254] == 4095
+
+
+def _vecmul_expect(oracle, u, v):
+    """VectorMultiply as the reference composes it (ml_kem.c:618-638): MultiplyNTTs per term, PolyAddition of the partial sums"""
+    out = np.zeros((u.shape[0], 256), np.uint16)
+    for i in range(u.shape[0]):
+        w = oracle.multiply_ntts(u[i, 0], v[i, 0])
+        for j in range(1, u.shape[1]):
+            w = oracle.poly_add(w, oracle.multiply_ntts(u[i, j], v[i, j]))
+        out[i] = w
+    return out
+
+
+def test_emu_poly_add_sub_and_vector_multiply(emu, oracle, golden_npz):
+    """SURVEY 8a rows a12 / a13 as stand-alone entries: PolyAddition / PolySubtraction against the reference-generated goldens
+    and (raw 12-bit inputs, ragged lengths) the oracle; VectorMultiply for k = 1..4 against MultiplyNTTs + PolyAddition."""
+    a, b = golden_npz["rand_a"].copy(), golden_npz["rand_b"].copy()
+    out = np.zeros_like(a)
+    emu.emu_poly_addsub(0, C.c_size_t(a.size), p16(a), p16(b), p16(out))
+    assert (out == golden_npz["rand_ab_add"]).all()
+    emu.emu_poly_addsub(1, C.c_size_t(a.size), p16(a), p16(b), p16(out))
+    assert (out == golden_npz["rand_ab_sub"]).all()
+    na, nb = golden_npz["nc_a"].copy(), golden_npz["nc_b"].copy()
+    junk = (na | 0xF000).astype(np.uint16)   # bits 12..15 are not part of the reference's field
+    for sub, fn in ((0, oracle.poly_add), (1, oracle.poly_sub)):
+        want = np.stack([fn(na[i], nb[i]) for i in range(na.shape[0])])
+        out = np.zeros_like(na)
+        emu.emu_poly_addsub(sub, C.c_size_t(na.size), p16(junk), p16(nb), p16(out))
+        assert (out == want).all(), sub
+        flat_a, flat_b = na.reshape(-1)[:1003].copy(), nb.reshape(-1)[:1003].copy()   # not a multiple of 8: scalar tail
+        o2 = np.zeros(1003, np.uint16)
+        emu.emu_poly_addsub(sub, C.c_size_t(1003), p16(flat_a), p16(flat_b), p16(o2))
+        assert (o2 == want.reshape(-1)[:1003]).all(), sub
+    rng = np.random.default_rng(618)
+    for k in (1, 2, 3, 4):
+        for hi in (3329, 4096):
+            u = rng.integers(0, hi, (5, k, 256)).astype(np.uint16)
+            v = rng.integers(0, hi, (5, k, 256)).astype(np.uint16)
+            w = np.zeros((5, 256), np.uint16)
+            assert emu.emu_vecmul(k, C.c_size_t(5), p16(u), p16(v), p16(w)) == 0
+            assert (w == _vecmul_expect(oracle, u, v)).all(), (k, hi)
+    assert emu.emu_vecmul(5, C.c_size_t(1), p16(a), p16(b), p16(out)) == -1

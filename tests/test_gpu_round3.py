@@ -1,0 +1,308 @@
+"""GPU tier (-m gpu), round-3 additions: BASELINE configs[4] at its stated shape on the one GPU (2^23 items, 8 members,
+item -> member i >> 20), the in-process and per-rank forms of bench.py's N > 1 line, row-level parity for SURVEY 8a rows
+a12 / a13 (PolyAddition / PolySubtraction / VectorMultiply), release of the cached host state while calls are in flight,
+stream ordering of the device-resident multi-member calls."""
+import json
+import os
+import socket
+import subprocess
+import sys
+import threading
+
+import numpy as np
+import pytest
+
+import __graft_entry__ as ge
+from conftest import seeds
+from oracle.loader import SIZES
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def torch():
+    import torch
+    assert torch.cuda.is_available(), "GPU tier needs a HIP device"
+    return torch
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    p = ge.load_package()
+    p.load_library()
+    return p
+
+
+@pytest.fixture(scope="module")
+def eng(pkg, torch):
+    e = pkg.MLKEM(768, device=0, chunk_items=4096)
+    yield e
+    e.close()
+
+
+def dev(torch, a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def host(t):
+    return t.cpu().numpy()
+
+
+def as_u16(t):
+    return host(t).view(np.uint16)
+
+
+# ---- SURVEY 8a rows a12 / a13 as their own entries ----------------------------------------------------------------------
+def test_poly_add_sub_golden_and_raw_12bit(eng, torch, oracle, golden_npz):
+    """PolyAddition / PolySubtraction (ml_kem.c:580-613) against the goldens the real reference generated (rand_ab_add,
+    rand_ab_sub) and, on raw 12-bit inputs with junk in bits 12..15 and a length that is not a multiple of 8, the oracle."""
+    a, b = golden_npz["rand_a"], golden_npz["rand_b"]
+    da, db = dev(torch, a.view(np.int16)), dev(torch, b.view(np.int16))
+    assert (as_u16(eng.poly_add(da, db)) == golden_npz["rand_ab_add"]).all()
+    assert (as_u16(eng.poly_sub(da, db)) == golden_npz["rand_ab_sub"]).all()
+    na, nb = golden_npz["nc_a"], golden_npz["nc_b"]
+    junk = (na | 0xF000).astype(np.uint16)
+    want_add = np.stack([oracle.poly_add(na[i], nb[i]) for i in range(na.shape[0])])
+    want_sub = np.stack([oracle.poly_sub(na[i], nb[i]) for i in range(na.shape[0])])
+    assert (as_u16(eng.poly_add(dev(torch, junk.view(np.int16)), dev(torch, nb.view(np.int16)))) == want_add).all()
+    assert (as_u16(eng.poly_sub(dev(torch, junk.view(np.int16)), dev(torch, nb.view(np.int16)))) == want_sub).all()
+    # C-ABI directly, ragged value count (scalar tail), in place
+    lib = eng.lib
+    x = dev(torch, na.reshape(-1)[:1003].copy().view(np.int16))
+    y = dev(torch, nb.reshape(-1)[:1003].copy().view(np.int16))
+    torch.cuda.synchronize()
+    assert lib.mlkem_poly_sub_dev(eng._ctx, 1003, x.data_ptr(), y.data_ptr(), x.data_ptr(), None) == 0
+    torch.cuda.synchronize()
+    assert (as_u16(x) == want_sub.reshape(-1)[:1003]).all()
+    assert lib.mlkem_poly_add_dev(eng._ctx, 8, None, y.data_ptr(), x.data_ptr(), None) == -101
+    # the extremes of the 12-bit field
+    e = np.zeros((3, 256), np.uint16)
+    f = np.zeros((3, 256), np.uint16)
+    e[0], f[0] = 0, 4095
+    e[1], f[1] = 4095, 4095
+    e[2], f[2] = 4095, 0
+    for fn, orc in ((eng.poly_add, oracle.poly_add), (eng.poly_sub, oracle.poly_sub)):
+        got = as_u16(fn(dev(torch, e.view(np.int16)), dev(torch, f.view(np.int16))))
+        assert (got == np.stack([orc(e[i], f[i]) for i in range(3)])).all()
+
+
+def test_vector_multiply_every_k(pkg, eng, torch, oracle, golden_npz):
+    """VectorMultiply (ml_kem.c:618-638) for k = 1..4 against the reference's own composition MultiplyNTTs + PolyAddition
+    (oracle), canonical and raw 12-bit operands; k = 1 on the golden pair equals the MultiplyNTTs golden."""
+    a, b = golden_npz["rand_a"], golden_npz["rand_b"]
+    got = as_u16(eng.vector_multiply(dev(torch, a.view(np.int16)[:, None, :]), dev(torch, b.view(np.int16)[:, None, :])))
+    assert (got == golden_npz["rand_ab_mul"]).all()
+    rng = np.random.default_rng(618)
+    for k in (1, 2, 3, 4):
+        for hi in (3329, 4096):
+            n = 37
+            u = rng.integers(0, hi, (n, k, 256)).astype(np.uint16)
+            v = rng.integers(0, hi, (n, k, 256)).astype(np.uint16)
+            want = np.zeros((n, 256), np.uint16)
+            for i in range(n):
+                w = oracle.multiply_ntts(u[i, 0], v[i, 0])
+                for j in range(1, k):
+                    w = oracle.poly_add(w, oracle.multiply_ntts(u[i, j], v[i, j]))
+                want[i] = w
+            got = as_u16(eng.vector_multiply(dev(torch, u.view(np.int16)), dev(torch, v.view(np.int16))))
+            assert (got == want).all(), (k, hi)
+    with pytest.raises(pkg.MLKEMError):
+        eng.vector_multiply(torch.zeros((1, 5, 256), dtype=torch.int16), torch.zeros((1, 5, 256), dtype=torch.int16))
+
+
+# ---- BASELINE configs[4] at its stated shape, on the one GPU --------------------------------------------------------------
+def test_config4_shape_2p23_items_8_members(pkg, torch, oracle):
+    """configs[4]: ML-KEM-768, batch 2^23 sharded over 8 members, item i -> member i >> 20, no exchange between members.
+    All eight members live on device 0 here (each with its own stream and engine context: the in-process form of the shard;
+    on the 8-GPU node member r sits on device r).  Checked over the whole batch: K_encaps == K_decaps for every item, status 0,
+    one tampered ciphertext per 1024 rejected; byte for byte against the oracle: the items on both sides of every member
+    boundary and the two ends of the batch."""
+    import bench
+    free, _ = torch.cuda.mem_get_info()
+    if free < 110 << 30:
+        pytest.skip("needs 110 GB of free HBM")
+    members, per = 8, 1 << 20
+    n = members * per
+    mm = pkg.MLKEMMulti(768, devices=[0] * members)
+    assert mm.ranges(n) == [(r << 20, (r + 1) << 20) for r in range(members)]          # i -> member i >> 20
+    dv = torch.device("cuda", 0)
+    d, z, m = ([bench.device_seeds(lbl, r * per, per, dv) for r in range(members)] for lbl in ("mlkem-bench-d", "mlkem-bench-z", "mlkem-bench-m"))
+    ek, dk = mm.keygen_dev(d, z)
+    c, K = mm.encaps_dev(ek, m)
+    Kd, st = mm.decaps_dev(dk, c)
+    mm.sync()
+    for r in range(members):
+        assert torch.equal(K[r], Kd[r]) and int(st[r].abs().max()) == 0, r
+    # implicit rejection: one tampered ciphertext per 1024 items, in every member
+    idx = torch.arange(0, per, 1024, device=dv)
+    ct = []
+    for r in range(members):
+        t = c[r].clone()
+        t[idx, (idx * 13 + r) % mm.c_len] ^= 1 << (r % 8)
+        ct.append(t)
+    Kt, stt = mm.decaps_dev(dk, ct)
+    mm.sync()
+    for r in range(members):
+        same = (Kt[r] == K[r]).all(dim=1)
+        assert not bool(same[idx].any()) and int(same.sum()) == per - idx.numel() and int(stt[r].abs().max()) == 0, r
+    # oracle at every member boundary: last item of member r and first item of member r + 1, plus both ends of the batch
+    edge = torch.tensor([0, 1, 1024, per - 2, per - 1], device=dv)   # items 0 and 1024 carry a tampered ciphertext
+    for r in range(members):
+        dh, zh, mh = host(d[r][edge]), host(z[r][edge]), host(m[r][edge])
+        ek_o, dk_o = oracle.keygen(768, dh, zh)
+        c_o, K_o = oracle.encaps(768, ek_o, mh)
+        assert (host(ek[r][edge]) == ek_o).all() and (host(dk[r][edge]) == dk_o).all(), r
+        assert (host(c[r][edge]) == c_o).all() and (host(K[r][edge]) == K_o).all(), r
+        Kt_o, st_o = oracle.decaps(768, dk_o, host(ct[r][edge]))
+        assert (host(Kt[r][edge]) == Kt_o).all() and (st_o == 0).all(), r
+        assert (Kt_o[0] != K_o[0]).any() and (Kt_o[2] != K_o[2]).any() and (Kt_o[[1, 3, 4]] == K_o[[1, 3, 4]]).all()
+    # the shards are the global batch: member r's first items are the documented expander at global index r * 2^20 + i
+    for r in (0, 3, 7):
+        want = np.frombuffer(b"".join(bench.expand("mlkem-bench-m", r * per + i) for i in range(4)), np.uint8).reshape(4, 32)
+        assert (host(m[r][:4]) == want).all()
+    mm.close()
+    del ek, dk, c, K, Kd, st, ct, Kt, stt, d, z, m
+    torch.cuda.empty_cache()
+
+
+def test_multi_dev_calls_are_ordered_behind_torch_producers(pkg, torch, oracle):
+    """the members enqueue on their own streams.  The wrapper makes those wait for torch's current stream, so
+    a device-resident call may follow the torch ops that produce its inputs WITHOUT a synchronize, and outputs dropped
+    before sync() stay allocated for the member stream."""
+    n = 4096
+    mm = pkg.MLKEMMulti(512, devices=[0, 0, 0], chunk_items=512)
+    rg = mm.ranges(n)
+    base = dev(torch, seeds("ord-d", n, 512))
+    torch.cuda.synchronize()
+    for trial in range(3):
+        # inputs are produced by a chain of torch kernels immediately before the call
+        big = torch.zeros((n, 32), dtype=torch.uint8, device="cuda")
+        for _ in range(20):
+            big = big + 1
+        ds = [(base[lo:hi] ^ (big[lo:hi] - 20 + trial)).contiguous() for lo, hi in rg]
+        zs = [(t ^ 0x5A).contiguous() for t in ds]
+        eks, dks = mm.keygen_dev(ds, zs)
+        cs, Ks = mm.encaps_dev(eks, zs)
+        del eks                                        # dropped before sync(): must not be recycled under the member
+        junk = [torch.full((hi - lo, 800), 0xEE, dtype=torch.uint8, device="cuda") for lo, hi in rg]
+        Kd, st = mm.decaps_dev(dks, cs)
+        mm.sync()
+        d_h = host(base) ^ np.uint8(trial)
+        ek_o, dk_o = oracle.keygen(512, d_h[:64], d_h[:64] ^ 0x5A)
+        c_o, K_o = oracle.encaps(512, ek_o, d_h[:64] ^ 0x5A)
+        assert (host(dks[0][:64]) == dk_o).all() and (host(cs[0][:64]) == c_o).all() and (host(Ks[0][:64]) == K_o).all()
+        assert all(torch.equal(a, b) for a, b in zip(Ks, Kd)) and all(int(s.abs().max()) == 0 for s in st)
+        del junk
+    assert len(mm.streams()) == 3
+    mm.close()
+
+
+# ---- release of the cached host state while calls are in flight ------------------------------------------------------------
+def test_host_release_races_with_calls_in_flight(pkg, oracle):
+    """Two threads keep calling host-pointer entry points (streaming KEM + a primitive) while a third keeps calling
+    mlkem_host_release() / mlkem_stream_release(): every call returns 0 with the right bytes (the state is reference-counted;
+    a release waits on the per-device locks and an overlapping call rebuilds what it needs)."""
+    lib = pkg.load_library()
+    stop = threading.Event()
+    bad = []
+    n = 257
+    d, z = seeds("race-d", n, 3), seeds("race-z", n, 3)
+    ek_o, dk_o = oracle.keygen(768, d[:16], z[:16])
+    f = np.random.default_rng(9).integers(0, 3329, (9, 256)).astype(np.uint16)
+    fh_o = oracle.ntt(f)
+
+    def kem_caller():
+        for _ in range(25):
+            ek, dk = np.zeros((n, 1184), np.uint8), np.zeros((n, 2400), np.uint8)
+            rc = lib.mlkem_keygen_stream(768, n, d.ctypes.data, z.ctypes.data, ek.ctypes.data, dk.ctypes.data, 64)
+            if rc != 0 or not (ek[:16] == ek_o).all() or not (dk[:16] == dk_o).all():
+                bad.append(("keygen", rc))
+
+    def prim_caller():
+        for _ in range(60):
+            fh = np.zeros_like(f)
+            rc = lib.mlkem_ntt(9, f.ctypes.data, fh.ctypes.data)
+            if rc != 0 or not (fh == fh_o).all():
+                bad.append(("ntt", rc))
+
+    def releaser():
+        while not stop.is_set():
+            lib.mlkem_host_release()
+            lib.mlkem_stream_release()
+
+    ts = [threading.Thread(target=kem_caller), threading.Thread(target=prim_caller)]
+    rel = threading.Thread(target=releaser)
+    rel.start()
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    stop.set()
+    rel.join()
+    assert not bad, bad[:5]
+    lib.mlkem_host_release()
+
+
+# ---- bench.py: the N > 1 line carries what configs[4] is defined by --------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _one_json_line(r):
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    return json.loads(lines[0])
+
+
+def test_bench_two_rank_line_carries_per_gpu(tmp_path):
+    """`bench.py --gpus 2` as the driver launches it: per_gpu has one entry per rank (own rate, own ms/step, device, clock and
+    power sampled on that rank), `correct` is the AND over the ranks, the aggregate is the MAX-elapsed figure."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--batch", "8192", "--rehearse"], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    j = _one_json_line(r)
+    assert j["n_gpus"] == 2 and j["correct"] is True and len(j["per_gpu"]) == 2
+    for rank, p in enumerate(j["per_gpu"]):
+        assert p["rank"] == rank and p["device"] == 0 and p["correct"] is True and p["value"] > 0 and p["ms_per_step"] > 0
+        assert set(p) >= {"rank", "device", "name", "value", "ms_per_step", "sclk_mhz", "socket_w", "correct"}
+        assert p["ms_per_step"] <= j["ms_per_step"] * 1.001          # a rank's own time is inside the MAX-over-ranks region
+    assert abs(j["value"] - 2 * 8192 * 2 / (j["ms_per_step"] * 2e-3)) / j["value"] < 1e-6
+
+
+def test_bench_inproc_members_line(tmp_path):
+    """`bench.py --inproc --gpus 3`: one process, three members through mlkem_{encaps,decaps}_multi_dev (all on device 0
+    here), per-member times from events on the members' own streams."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--inproc", "--gpus", "3", "--steps", "2", "--warmup", "1",
+                        "--batch", "8192"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    j = _one_json_line(r)
+    assert j["n_gpus"] == 3 and j["correct"] is True and len(j["per_gpu"]) == 3 and j["scaling"] == "weak"
+    assert "inproc" in j["config"]["parallelism"] and "REHEARSAL" in j["config"]["parallelism"]
+    assert j["config"]["member_devices"] == [0, 0, 0]
+    assert all(p["correct"] and p["value"] > 0 for p in j["per_gpu"])
+    assert abs(j["value"] - 3 * 8192 * 2 / (j["ms_per_step"] * 2e-3)) / j["value"] < 1e-6
+
+
+def test_bench_default_line_has_three_cpu_legs(tmp_path):
+    """the N = 1 line: cpu_baseline carries reference -O2, reference -O0 (the reference makefile's flags) and the port, each
+    with its core count and a byte comparison against the GPU; the roofline is the dominant kernel's by the algorithmic-bytes
+    rule with the whole-pass figure beside it.  Small batch, no `also` legs: this checks the plumbing, not the numbers."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", "16384", "--no-also"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT)
+    j = _one_json_line(r)
+    cb = j["cpu_baseline"]
+    assert cb["outputs_match_gpu"] is True and cb["cores"] >= 1
+    legs = cb["legs"]
+    assert "port" in legs and legs["port"]["kind"] == "port" and legs["port"]["outputs_match_gpu"] is True
+    if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libmlkem_ref.so")):
+        assert cb["kind"] == "reference" and legs["reference_O2"]["outputs_match_gpu"] is True
+        assert legs["reference_O0"]["outputs_match_gpu"] is True and "-g" in legs["reference_O0"]["flags"]
+        assert legs["reference_O0"]["per_core"] < legs["reference_O2"]["per_core"] < legs["port"]["per_core"]
+    rf = j["roofline"]
+    assert rf["dominant_kernel"] and rf["whole_pass"]["frac"] <= rf["frac"] < 1 and len(j["per_gpu"]) == 1

@@ -118,3 +118,17 @@ def test_inverse_ntt_above_q_is_undefined_in_the_reference(oracle):
     one = np.zeros(256, np.uint16)
     one[0] = 4095
     assert np.asarray(r2.ntt(one)).ravel()[254] == 4095 == np.asarray(r0.ntt(one)).ravel()[254] == oracle.ntt(one).ravel()[254]
+
+
+def test_poly_add_sub_raw_12bit_inputs_oracle_equals_reference(ref, oracle):
+    """PolyAddition / PolySubtraction (ml_kem.c:580-613) on every kind of 12-bit input, also above q where the subtraction's
+    `Q - (v - u)` wraps in the reference's 12-bit field: oracle == live reference."""
+    rng = np.random.default_rng(580)
+    a = rng.integers(0, 4096, (8, 256)).astype(np.uint16)
+    b = rng.integers(0, 4096, (8, 256)).astype(np.uint16)
+    a[0], b[0] = 0, 4095
+    a[1], b[1] = 4095, 4095
+    a[2], b[2] = 4095, 0
+    for i in range(8):
+        assert (oracle.poly_add(a[i], b[i]) == ref.poly_add(a[i], b[i])).all()
+        assert (oracle.poly_sub(a[i], b[i]) == ref.poly_sub(a[i], b[i])).all()
