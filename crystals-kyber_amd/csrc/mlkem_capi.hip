@@ -1085,8 +1085,38 @@ struct mlkem_multi {
 
 namespace {
 
+// Member streams come from a per-device pool that lives as long as the process (like the stream pools of the frameworks
+// that sit on top of this library): a stream handed out through mlkem_multi_stream() may have been recorded in a caller's
+// allocator (torch's record_stream) or events, and those outlive the mlkem_multi.  mlkem_multi_destroy() synchronises the
+// stream and puts it back; nothing ever destroys it.
+struct StreamPool {
+    std::mutex mu;
+    std::map<int, std::vector<std::pair<hipStream_t, bool>>> per_dev;   // (stream, in use)
+};
+StreamPool& stream_pool() {
+    static StreamPool* p = new StreamPool();   // leaked on purpose: no HIP calls during static destruction
+    return *p;
+}
+hipStream_t pool_acquire(int dev) {   // `dev` is current
+    StreamPool& P = stream_pool();
+    std::lock_guard<std::mutex> lock(P.mu);
+    auto& v = P.per_dev[dev];
+    for (auto& e : v)
+        if (!e.second) { e.second = true; return e.first; }
+    hipStream_t s = nullptr;
+    if (!hip_ok(hipStreamCreateWithFlags(&s, hipStreamNonBlocking), "hipStreamCreate")) return nullptr;
+    v.emplace_back(s, true);
+    return s;
+}
+void pool_release(int dev, hipStream_t s) {
+    StreamPool& P = stream_pool();
+    std::lock_guard<std::mutex> lock(P.mu);
+    for (auto& e : P.per_dev[dev])
+        if (e.first == s) e.second = false;
+}
+
 int member_ready(mlkem_multi* mm, mlkem_multi::Member& m) {   // m.device is current
-    if (!m.st && !hip_ok(hipStreamCreateWithFlags(&m.st, hipStreamNonBlocking), "hipStreamCreate")) return MLKEM_ERR_NO_DEVICE;
+    if (!m.st && !(m.st = pool_acquire(m.device))) return MLKEM_ERR_NO_DEVICE;
     if (!m.ctx) return mlkem_ctx_create(&m.ctx, m.device, mm->chunk);
     return MLKEM_OK;
 }
@@ -1174,7 +1204,7 @@ void mlkem_multi_destroy(mlkem_multi* mm) {
         (void)g.enter(m->device);
         if (m->st) (void)hipStreamSynchronize(m->st);
         if (m->ctx) mlkem_ctx_destroy(m->ctx);
-        if (m->st) (void)hipStreamDestroy(m->st);
+        if (m->st) pool_release(m->device, m->st);   // synchronised above; the stream itself lives on (see StreamPool)
         engine_release(m->eng);
         delete m;
     }
@@ -1252,14 +1282,15 @@ int mlkem_decaps_multi_dev(mlkem_multi* mm, int set, const size_t* n_shard, cons
                            uint8_t* const* K, int32_t* const* status) {
     return multi_dev(mm, 2, set, n_shard, dk, c, K, reinterpret_cast<void* const*>(status));
 }
-// the HIP stream member `member` enqueues its device-resident work on (created on first use): lets a caller order that
-// stream after the producers of its inputs (hipStreamWaitEvent) and time or consume the member's work with events
+// the HIP stream member `member` enqueues its device-resident work on (taken from the process-lifetime pool on first use):
+// lets a caller order that stream after the producers of its inputs (hipStreamWaitEvent) and time or consume the member's
+// work with events; the handle stays a valid stream after mlkem_multi_destroy
 void* mlkem_multi_stream(mlkem_multi* mm, int member) {
     if (!mm || member < 0 || member >= (int)mm->mem.size()) return nullptr;
     auto& m = *mm->mem[member];
     DeviceGuard g;
     if (!g.enter(m.device)) return nullptr;
-    if (!m.st && !hip_ok(hipStreamCreateWithFlags(&m.st, hipStreamNonBlocking), "hipStreamCreate")) return nullptr;
+    if (!m.st) m.st = pool_acquire(m.device);
     return m.st;
 }
 int mlkem_multi_sync(mlkem_multi* mm) {

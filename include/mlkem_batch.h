@@ -258,9 +258,11 @@ int mlkem_encaps_multi_dev(mlkem_multi* mm, int param_set, const size_t* n_shard
 int mlkem_decaps_multi_dev(mlkem_multi* mm, int param_set, const size_t* n_shard, const uint8_t* const* dk, const uint8_t* const* c,
                            uint8_t* const* K, int32_t* const* status);
 int mlkem_multi_sync(mlkem_multi* mm);
-/* The hipStream_t (as void*) member `member` enqueues its device-resident work on; created on first use, owned by the
- * mlkem_multi.  A caller orders it after the producers of its inputs (hipStreamWaitEvent on it) and times or consumes the
- * member's work with events recorded on it.  NULL on a bad argument. */
+/* The hipStream_t (as void*) member `member` enqueues its device-resident work on.  A caller orders it after the producers
+ * of its inputs (hipStreamWaitEvent on it) and times or consumes the member's work with events recorded on it.  Member
+ * streams come from a per-device pool that lives as long as the process: the handle remains a valid stream after
+ * mlkem_multi_destroy (which synchronises it and returns it to the pool), so allocator bookkeeping or events that still
+ * refer to it stay harmless.  NULL on a bad argument. */
 void* mlkem_multi_stream(mlkem_multi* mm, int member);
 
 /* ---- randomised wrappers: seeds drawn on the host with getrandom(2) ---------------- */
