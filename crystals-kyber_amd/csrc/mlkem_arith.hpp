@@ -20,22 +20,27 @@ namespace mlkem {
 #endif
 constexpr int ARITH_WAVES = MLKEM_ARITH_WAVES;   // waves per workgroup (each fully independent)
 // __launch_bounds__ second argument of the K-PKE kernels = resident waves per SIMD the register allocator aims at.  The
-// kernels hide their LDS-exchange latency with occupancy (A/B on one box, tools/ab_bench.sh: 6 waves beat 5 by 3-4 % in
-// k_encrypt<3>; a loop-over-items form with 13 % fewer instructions but 4 waves was slower): 6 where the LDS block allows
-// it (k = 2, 3: 18-24 KB per workgroup), 5 for k = 4 (30 KB).  MLKEM_ARITH_MINWAVES overrides for experiments.
+// kernels hide their LDS-exchange latency with occupancy (A/B on one box: 6 waves beat 5 by 3-4 % in k_encrypt<3>, 7 beat 6
+// by another 2-3 %, profiles/r03_kpke_experiments.txt; a loop-over-items form with 13 % fewer instructions but 4 waves was
+// slower): 7 where the LDS block allows it (k = 2, 3: 16-22 KB per workgroup; the build uses -fno-slp-vectorize, under which
+// k_encrypt<3> needs 66-69 VGPRs), 5 for k = 4 (28 KB).  MLKEM_ARITH_MINWAVES overrides for experiments.
 #ifdef MLKEM_ARITH_MINWAVES
 constexpr int arith_minwaves(int) { return MLKEM_ARITH_MINWAVES; }
 #else
-constexpr int arith_minwaves(int k) { return k == 4 ? 5 : 6; }
+constexpr int arith_minwaves(int k) { return k == 4 ? 5 : 7; }
 #endif
 
 template <int K>
 struct __attribute__((aligned(16))) ArithLds {
-    float xch[256];         // NTT exchange buffer
+    float xch[256];         // NTT exchange buffer; between transforms it doubles as the codec byte buffer (cbuf())
     float vhat[K][256];     // NTT-domain vector (y-hat or s-hat), reduced
     float vgam[K][128];     // its odd coefficients times gamma (ml_kem.c:402-403)
-    uint32_t cbuf[CODEC_BUF_WORDS];
+    // The codec byte buffer lives in the exchange buffer: a codec step never overlaps a transform of the same wave, both sides
+    // fence their LDS traffic, and a wave's DS operations execute in issue order.  5.5 instead of 5.9 KB per wave at k = 3, so
+    // that a seventh workgroup fits the CU's 160 KB.
+    __device__ __forceinline__ uint32_t* cbuf() { return reinterpret_cast<uint32_t*>(xch); }
 };
+static_assert(CODEC_BUF_WORDS * 4 <= 256 * 4, "the codec buffer must fit the exchange buffer");
 
 __device__ __forceinline__ void store_poly_nat(uint16_t* p, const int (&x)[4]) {
     uint2 v;
@@ -43,16 +48,7 @@ __device__ __forceinline__ void store_poly_nat(uint16_t* p, const int (&x)[4]) {
     v.y = ((uint32_t)x[2] & 0xFFFFu) | ((uint32_t)x[3] << 16);
     *reinterpret_cast<uint2*>(p + 4 * lane_id()) = v;
 }
-#ifndef MLKEM_EXP_A384
-#define MLKEM_EXP_A384 0
-#endif
-__device__ __forceinline__ uint2 load_poly_raw(const uint16_t* p) {
-#if MLKEM_EXP_A384   // TIMING EXPERIMENT ONLY (wrong results): the wave touches 384 of the polynomial's 512 bytes
-    return *reinterpret_cast<const uint2*>(p + 3 * lane_id());
-#else
-    return stream_load8(p + 4 * lane_id());
-#endif
-}
+__device__ __forceinline__ uint2 load_poly_raw(const uint16_t* p) { return stream_load8(p + 4 * lane_id()); }
 __device__ __forceinline__ void poly_raw_to_f(const uint2 v, float (&x)[4]) {
     x[0] = (float)(v.x & 0xFFFFu); x[1] = (float)(v.x >> 16);
     x[2] = (float)(v.y & 0xFFFFu); x[3] = (float)(v.y >> 16);
@@ -236,7 +232,7 @@ k_encrypt(size_t n, const uint8_t* __restrict__ ek, size_t ek_stride, const uint
         cbd_eval_f<2>(raw_e1[a], e);
 #pragma unroll
         for (int m = 0; m < 4; m++) acc[m] += e[m];
-        diff |= emit_compressed<DU, COMPARE>(L.cbuf, acc, COMPARE ? nullptr : my_c + a * 32 * DU, cu_ref);
+        diff |= emit_compressed<DU, COMPARE>(L.cbuf(), acc, COMPARE ? nullptr : my_c + a * 32 * DU, cu_ref);
         if constexpr (COMPARE) {
             if (a + 1 < K) codec_fetch<DU>(my_cin + (a + 1) * 32 * DU, cu_ref);
             else codec_fetch<DV>(my_cin + K * 32 * DU, cv_ref);
@@ -253,7 +249,7 @@ k_encrypt(size_t n, const uint8_t* __restrict__ ek, size_t ek_stride, const uint
 #pragma unroll
         for (int b = 0; b < K; b++) {
             float tv[4];
-            decode_regs<12, false>(L.cbuf, that[b], tv);   // raw 12-bit values (F3)
+            decode_regs<12, false>(L.cbuf(), that[b], tv);   // raw 12-bit values (F3)
 #pragma unroll
             for (int m = 0; m < 4; m++) over = over || (tv[m] >= F_Q);
             basemul_acc_f(acc, tv, L.vhat[b], L.vgam[b]);
@@ -267,7 +263,7 @@ k_encrypt(size_t n, const uint8_t* __restrict__ ek, size_t ek_stride, const uint
         cbd_eval_f<2>(raw_e2, e);
 #pragma unroll
         for (int m = 0; m < 4; m++) acc[m] += e[m] + (((mb >> m) & 1u) ? 1665.0f : 0.0f);   // Decompress_1(1) = 1665
-        diff |= emit_compressed<DV, COMPARE>(L.cbuf, acc, COMPARE ? nullptr : my_c + K * 32 * DU, cv_ref);
+        diff |= emit_compressed<DV, COMPARE>(L.cbuf(), acc, COMPARE ? nullptr : my_c + K * 32 * DU, cv_ref);
     }
     if constexpr (COMPARE) {
         // both candidates are read and blended by mask: neither a branch nor an address depends on whether the
@@ -324,7 +320,7 @@ k_keygen(size_t n, const uint16_t* __restrict__ A, const uint8_t* __restrict__ p
 #pragma unroll
         for (int m = 0; m < 4; m++) x[m] = fred(x[m]);
         stash_vhat_f(L.vhat[b], L.vgam[b], x, tw);
-        emit_encode12(L.cbuf, x, my_dk + 384 * b, nullptr);
+        emit_encode12(L.cbuf(), x, my_dk + 384 * b, nullptr);
     }
     wave_lds_fence();
     // t-hat[a] = sum_b A[a][b] o s-hat[b] + e-hat[a] (ml_kem.c:710-727), ek = ByteEncode_12(t-hat) || rho
@@ -349,7 +345,7 @@ k_keygen(size_t n, const uint16_t* __restrict__ A, const uint8_t* __restrict__ p
         wave_ntt_f(e, L.xch, tw);
 #pragma unroll
         for (int m = 0; m < 4; m++) acc[m] += e[m];   // <= 1665 + 6660
-        emit_encode12(L.cbuf, acc, my_ek + 384 * a, KEM_DK ? my_dk + 384 * K + 384 * a : (uint8_t*)nullptr);
+        emit_encode12(L.cbuf(), acc, my_ek + 384 * a, KEM_DK ? my_dk + 384 * K + 384 * a : (uint8_t*)nullptr);
     }
     if (l < 8) {
         reinterpret_cast<uint32_t*>(my_ek + 384 * K)[l] = rho_w;

@@ -128,39 +128,22 @@ int mlkem_ctx_create(mlkem_ctx** out, int device, size_t chunk_items) {
         if (v > 0) hn = (size_t)v;
     }
     if (hn < n) hn = n;
-    if (const char* e = getenv("MLKEM_RING")) { const int r = atoi(e); c->ws.ring = (r == 128 || r == 64 || r == 32) ? r : 0; }
-    // Sampler/arithmetic overlap on a helper stream is opt-in (MLKEM_OVERLAP=1): measured on MI355X it does not pay,
-    // because both kernel families are VALU-issue-bound (profiles/r02_sampler_experiments.txt: +1 % step time); it doubles the chunk scratch.
-    const char* ov = getenv("MLKEM_OVERLAP");
-    const bool overlap = ov && atoi(ov) == 1;
-    const size_t nbuf = overlap ? 2 : 1;
-    // carve one allocation: nbuf x (A | prf | leftover) | r | rho | m | Kp | Kbar, each 256-byte aligned
+    // carve one allocation: A | prf | leftover | resume | r | rho | m | Kp | Kbar, each 256-byte aligned
     auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
     const size_t rcap = n * 2 < 64 ? 64 : n * 2;   // resume records: 1/8 of the chunk's (up to 16 n) sponges, expected 0.8 %
     const size_t szA = up(n * 16 * 512), szP = up(n * 9 * 192), szL = up((n * 16 + 2) * 4), szR = up(rcap * RESUME_WORDS * 4), sz32 = up(hn * 32);
-    c->scratch_bytes = nbuf * (szA + szP + szL + szR) + 5 * sz32;
+    c->scratch_bytes = szA + szP + szL + szR + 5 * sz32;
     if (!hip_ok(hipMalloc(&c->scratch, c->scratch_bytes), "hipMalloc(scratch)")) {
         delete c;
         return MLKEM_ERR_ALLOC;
     }
     uint8_t* base = static_cast<uint8_t*>(c->scratch);
-    for (int b = 0; b < 2; b++) {
-        uint8_t* q = base + (size_t)(b % nbuf) * (szA + szP + szL + szR);
-        c->ws.A2[b] = reinterpret_cast<uint16_t*>(q);
-        c->ws.prf2[b] = q + szA;
-        c->ws.leftover2[b] = reinterpret_cast<uint32_t*>(q + szA + szP);
-        c->ws.resume2[b] = reinterpret_cast<uint32_t*>(q + szA + szP + szL);
-    }
-    c->ws.A = c->ws.A2[0]; c->ws.prf = c->ws.prf2[0]; c->ws.leftover = c->ws.leftover2[0]; c->ws.resume = c->ws.resume2[0];
+    c->ws.A = reinterpret_cast<uint16_t*>(base);
+    c->ws.prf = base + szA;
+    c->ws.leftover = reinterpret_cast<uint32_t*>(base + szA + szP);
+    c->ws.resume = reinterpret_cast<uint32_t*>(base + szA + szP + szL);
     c->ws.resume_cap = (uint32_t)rcap;
-    if (overlap) {
-        bool ok = hip_ok(hipStreamCreateWithFlags(&c->ws.helper, hipStreamNonBlocking), "hipStreamCreate");
-        for (int b = 0; b < 2 && ok; b++)
-            ok = hip_ok(hipEventCreateWithFlags(&c->ws.ev_sample[b], hipEventDisableTiming), "hipEventCreate") &&
-                 hip_ok(hipEventCreateWithFlags(&c->ws.ev_free[b], hipEventDisableTiming), "hipEventCreate");
-        if (!ok) c->ws.helper = nullptr;
-    }
-    c->ws.r = base + nbuf * (szA + szP + szL + szR);
+    c->ws.r = base + szA + szP + szL + szR;
     c->ws.rho = c->ws.r + sz32;
     c->ws.m = c->ws.rho + sz32;
     c->ws.Kp = c->ws.m + sz32;
@@ -176,14 +159,6 @@ void mlkem_ctx_destroy(mlkem_ctx* ctx) {
     int prev = -1;
     (void)hipGetDevice(&prev);
     (void)hipSetDevice(ctx->device);
-    if (ctx->ws.helper) {
-        (void)hipStreamSynchronize(ctx->ws.helper);
-        (void)hipStreamDestroy(ctx->ws.helper);
-        for (int b = 0; b < 2; b++) {
-            if (ctx->ws.ev_sample[b]) (void)hipEventDestroy(ctx->ws.ev_sample[b]);
-            if (ctx->ws.ev_free[b]) (void)hipEventDestroy(ctx->ws.ev_free[b]);
-        }
-    }
     if (ctx->scratch) {
         (void)hipMemset(ctx->scratch, 0, ctx->scratch_bytes);   // r, m', K', K-bar, PRF output: secret-dependent intermediates
         (void)hipFree(ctx->scratch);

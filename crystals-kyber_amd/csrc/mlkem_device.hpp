@@ -89,29 +89,15 @@ __device__ __forceinline__ void rotl64(uint32_t lo, uint32_t hi, uint32_t& olo, 
     }
 }
 
-// theta is applied in one of two forms (same result):
-//   MLKEM_KECCAK_DFORM 0 : A ^ C[x-1] ^ rotl(C[x+1], 1) as one v_bitop3 per half-lane; C and rotl(C) (20 registers) stay
-//                          live through rho/pi  -> 180 VALU per round, 78 VGPRs for the bare permutation
-//   MLKEM_KECCAK_DFORM 1 : D[x] = C[x-1] ^ rotl(C[x+1], 1) materialised first (10 registers live), then A ^ D
-//                          -> 190 VALU per round but a smaller live set
-#ifndef MLKEM_KECCAK_DFORM
-#define MLKEM_KECCAK_DFORM 0
-#endif
-#if MLKEM_KECCAK_DFORM
-#define MLKEM_RHOPI(dst, src, rot, dx)                                                       \
-    {                                                                                        \
-        uint32_t tl = s.lo[src] ^ dl[dx];                                                    \
-        uint32_t th = s.hi[src] ^ dh[dx];                                                    \
-        rotl64<rot>(tl, th, bl[dst], bh[dst]);                                               \
-    }
-#else
+// theta-apply + rho + pi of one lane: A ^ C[x-1] ^ rotl(C[x+1], 1) as one v_bitop3 per half-lane (C and rotl(C), 20
+// registers, stay live through rho / pi: 180 VALU per round, 78 VGPRs for the bare permutation; materialising D first needs
+// 10 more instructions per round and saved no registers in practice)
 #define MLKEM_RHOPI(dst, src, rot, dx)                                                       \
     {                                                                                        \
         uint32_t tl = MLKEM_XOR3(s.lo[src], cl[(dx + 4) % 5], rl[(dx + 1) % 5]);             \
         uint32_t th = MLKEM_XOR3(s.hi[src], ch[(dx + 4) % 5], rh[(dx + 1) % 5]);             \
         rotl64<rot>(tl, th, bl[dst], bh[dst]);                                               \
     }
-#endif
 
 __device__ __forceinline__ void keccak_f1600(KeccakState& s) {
 #pragma unroll 1
@@ -125,14 +111,6 @@ __device__ __forceinline__ void keccak_f1600(KeccakState& s) {
         }
 #pragma unroll
         for (int x = 0; x < 5; x++) rotl64<1>(cl[x], ch[x], rl[x], rh[x]);
-#if MLKEM_KECCAK_DFORM
-        uint32_t dl[5], dh[5];
-#pragma unroll
-        for (int x = 0; x < 5; x++) {
-            dl[x] = cl[(x + 4) % 5] ^ rl[(x + 1) % 5];
-            dh[x] = ch[(x + 4) % 5] ^ rh[(x + 1) % 5];
-        }
-#endif
         // theta-apply + rho (sha3.c:53-84) + pi (sha3.c:88-112): B[y, 2x+3y] = rotl(A[x, y] ^ D[x], r[x, y])
         MLKEM_RHOPI(0, 0, 0, 0)   MLKEM_RHOPI(10, 1, 1, 1)  MLKEM_RHOPI(20, 2, 62, 2) MLKEM_RHOPI(5, 3, 28, 3)  MLKEM_RHOPI(15, 4, 27, 4)
         MLKEM_RHOPI(16, 5, 36, 0) MLKEM_RHOPI(1, 6, 44, 1)  MLKEM_RHOPI(11, 7, 6, 2)  MLKEM_RHOPI(21, 8, 55, 3) MLKEM_RHOPI(6, 9, 20, 4)
@@ -179,7 +157,7 @@ __device__ __forceinline__ uint32_t& keccak_word(KeccakState& s) {
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 // Single-use streams of the K-PKE kernels: the sampled matrix A-hat (written once by the sampler, read once, 1.2-2.5 GB per
 // chunk: far beyond the 4 MB L2 of an XCD) and the packed key / ciphertext rows.  MLKEM_A_NT is a bit set: 1 = A-hat loads,
-// 4 = packed-row loads carry the non-temporal hint (A/B on one box, tools/ab_bench.sh: -0.4..-0.7 % step time, at the edge of
+// 4 = packed-row loads carry the non-temporal hint (A/B on one box, tools/ab_run.py: -0.4..-0.7 % step time, at the edge of
 // the noise); 2 = the sampler's A-hat stores as well: those are 32-byte pieces of a lane's own row, and as non-temporal
 // stores they are no longer merged in L2 - k_sample_main 1.12 -> 3.73 ms.  Default 5.
 #ifndef MLKEM_A_NT

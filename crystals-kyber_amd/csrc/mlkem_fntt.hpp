@@ -40,20 +40,11 @@ __device__ __forceinline__ float fmulmod_shoup(Tw w, float b) {
     const float nkq = __builtin_fmaf(km, -F_Q, F_MAGIC_Q);
     return __builtin_fmaf(b, w.z, nkq);
 }
-// Measured on MI355X: the 3-FMA form removes 6.5 % of the arithmetic kernels' VALU instructions
-// but needs the (zeta, zeta/q) pairs in registers (+10..18 VGPRs) and the kernels get 3-5 % SLOWER in the power-capped
-// full pass; the NTT-only kernels do not change.  It is therefore compiled in only with MLKEM_TW3=1; the default keeps
-// mul + Barrett (the quotient halves of the twiddle pairs are dead code then).
-#ifndef MLKEM_TW3
-#define MLKEM_TW3 0
-#endif
-__device__ __forceinline__ float fmulmod(Tw w, float b) {
-#if MLKEM_TW3
-    return fmulmod_shoup(w, b);
-#else
-    return fred(w.z * b);
-#endif
-}
+// Which product where (measured on MI355X, DESIGN.md section 4, profiles/r03_kpke_experiments.txt): a twiddle that is a
+// compile-time constant or sits in a register pair anyway takes the 3-FMA form (fmulmod_shoup: the register transforms of
+// mlkem_rntt.hpp, the two outermost layers here); the per-lane twiddles of the LDS transforms take mul + Barrett, because
+// carrying their quotient halves costs 10-18 VGPRs of a kernel that lives on occupancy.
+__device__ __forceinline__ float fmulmod(Tw w, float b) { return fred(w.z * b); }
 constexpr Tw tw_const(int zeta_centred) { return Tw{(float)zeta_centred, (float)((double)zeta_centred / 3329.0)}; }
 __device__ __forceinline__ Tw tw_neg(Tw w) { return Tw{-w.z, -w.zq}; }
 // canonical representative in [0, q) as an integer, for |x| <= 2^24

@@ -101,100 +101,31 @@ inline bool param_set(int set, ParamSet& p) {
 //   resume   208*(k*k)/8   saved sponges (index, count, Keccak state) that need a 4th squeeze block: room for 1/8 of all
 //                      sponges (expected: 0.8 %), the overflow goes to the restart list
 // Per h-chunk item: r, rho, m, Kp, Kbar : 32 bytes each.
-#ifdef MLKEM_EMU
-using event_t = void*;
-inline void ev_record(event_t, stream_t) {}
-inline void stream_wait(stream_t, event_t) {}
-#else
-using event_t = hipEvent_t;
-inline void ev_record(event_t e, stream_t s) { (void)hipEventRecord(e, s); }
-inline void stream_wait(stream_t s, event_t e) { (void)hipStreamWaitEvent(s, e, 0); }
-#endif
-
 struct Workspace {
-    uint16_t* A = nullptr;      // current chunk buffer (set by view())
+    uint16_t* A = nullptr;      // sampled matrices of one chunk
     uint8_t *prf = nullptr, *r = nullptr, *rho = nullptr, *m = nullptr, *Kp = nullptr, *Kbar = nullptr;
     uint32_t* leftover = nullptr;
     uint32_t* resume = nullptr;
     uint32_t resume_cap = 0;    // records `resume` has room for
-    // the chunk scratch exists twice so that the sampler of chunk i+1 (caller's stream) can run while the
-    // arithmetic kernel of chunk i (helper stream) still reads chunk i's matrix: ChunkPipe below
-    uint16_t* A2[2] = {nullptr, nullptr};
-    uint8_t* prf2[2] = {nullptr, nullptr};
-    uint32_t* leftover2[2] = {nullptr, nullptr};
-    uint32_t* resume2[2] = {nullptr, nullptr};
-    stream_t helper = nullptr;                        // nullptr: no overlap, everything on the caller's stream
-    event_t ev_sample[2] = {nullptr, nullptr}, ev_free[2] = {nullptr, nullptr};
     size_t cap = 0;    // chunk capacity (items) of A / prf / leftover
     size_t hcap = 0;   // h-chunk capacity (items) of the 32-byte arrays
-    int ring = 0;      // sampler staging: 0 = linear buffer + EXEC-masked acceptance (default), or an LDS ring of 32 / 64 / 128
-                       // coefficients per lane (the r01 forms, kept for A/B measurements: MLKEM_RING)
     int fips = 0;      // 0: bit-identical to the reference (PRF, J on SHAKE128; no-op modulus check)
                        // 1: FIPS 203 conformant (PRF, J on SHAKE256; encaps reports status -4 for t-hat coefficients >= q)
-    Workspace view(int b) const {
-        Workspace w = *this;
-        w.A = A2[b]; w.prf = prf2[b]; w.leftover = leftover2[b]; w.resume = resume2[b];
-        return w;
-    }
 };
-
-// Two-stream software pipeline over the chunks of one h-chunk: sampler on `main`, polynomial arithmetic on the helper
-// stream, two scratch buffers, fork/join by events (capturable in a hipGraph; no host synchronisation).
-struct ChunkPipe {
-    const Workspace& ws;
-    stream_t main;
-    bool overlap;
-    int i = 0;
-    stream_t last_arith = nullptr;
-    ChunkPipe(const Workspace& w, stream_t st, size_t nchunks) : ws(w), main(st), overlap(w.helper != nullptr && nchunks > 1) {}
-    int begin_chunk() {                       // buffer for the next chunk; `main` waits until its previous user is done
-        const int b = overlap ? (i & 1) : 0;
-        if (overlap && i >= 2) stream_wait(main, ws.ev_free[b]);
-        return b;
-    }
-    stream_t arith_stream(int b) {            // stream for the arithmetic kernel, ordered behind the sampler
-        if (!overlap) return main;
-        ev_record(ws.ev_sample[b], main);
-        stream_wait(ws.helper, ws.ev_sample[b]);
-        return ws.helper;
-    }
-    void end_chunk(int b) {
-        if (overlap) ev_record(ws.ev_free[b], ws.helper);
-        i++;
-    }
-    void join() {                             // `main` continues only after every arithmetic kernel has finished
-        if (!overlap) return;
-        stream_wait(main, ws.ev_free[0]);
-        if (i >= 2) stream_wait(main, ws.ev_free[1]);
-    }
-};
+// Everything of one call runs on the caller's stream, chunk after chunk: sampler -> leftover passes -> arithmetic.  A
+// two-stream pipeline (arithmetic of chunk i beside the sampler of chunk i + 1, also with the arithmetic confined to a subset
+// of the CUs) and a phase-separated schedule were measured and do not pay: the pass is energy-limited
+// (profiles/r02_sampler_experiments.txt, profiles/r03_power_schedule.txt).
 
 inline size_t ceil_div(size_t a, size_t b) { return (a + b - 1) / b; }
 inline size_t min_sz(size_t a, size_t b) { return a < b ? a : b; }
 
-// SampleNTT for the k x k matrix + PRF rows of `n` items: the three-block main kernel, then the general kernel over
-// the leftover list (ml_kem.c:189-245, :496-515)
+// SampleNTT for the k x k matrix + PRF rows of `n` items: the three-block main kernel, then the leftover passes
+// (ml_kem.c:189-245, :496-515)
 // n_xof_items / n_prf_items: items whose matrix / PRF rows are produced (equal except for shared-key batches, where the
 // matrix is sampled once and the PRF rows per item)
-// `tail_st`: stream of the leftover pass.  It only has to finish before the arithmetic kernel that consumes the matrix, so
-// the chunk loops put it on the arithmetic stream: with MLKEM_OVERLAP=1 that is the helper stream and the (latency-bound,
-// one wave per CU) leftover pass runs beside the next chunk's three-block kernel instead of in front of it.
-inline void launch_sample_split(stream_t st, stream_t tail_st, const ParamSet& p, size_t n_xof_items, size_t n_prf_items, const uint8_t* rho,
-                                size_t rho_stride, int transpose, const uint8_t* r, int prf_per_item, int n_eta1, const Workspace& ws,
-                                ChunkPipe* pipe = nullptr, int buf = 0);
-inline void launch_sample(stream_t st, const ParamSet& p, size_t n, const uint8_t* rho, size_t rho_stride, int transpose,
-                          const uint8_t* r, int prf_per_item, int n_eta1, const Workspace& ws) {
-    launch_sample_split(st, st, p, n, n, rho, rho_stride, transpose, r, prf_per_item, n_eta1, ws);
-}
-// the chunk loops' form: three-block kernel on `st`, leftover pass on the arithmetic stream, which is returned
-inline stream_t launch_sample_piped(stream_t st, ChunkPipe& pipe, int buf, const ParamSet& p, size_t n, const uint8_t* rho, size_t rho_stride,
-                                    int transpose, const uint8_t* r, int prf_per_item, int n_eta1, const Workspace& ws) {
-    launch_sample_split(st, nullptr, p, n, n, rho, rho_stride, transpose, r, prf_per_item, n_eta1, ws, &pipe, buf);
-    return pipe.last_arith;
-}
-inline void launch_sample_split(stream_t st, stream_t tail_st, const ParamSet& p, size_t n_xof_items, size_t n_prf_items, const uint8_t* rho,
-                                size_t rho_stride, int transpose, const uint8_t* r, int prf_per_item, int n_eta1, const Workspace& ws,
-                                ChunkPipe* pipe, int buf) {
+inline void launch_sample_split(stream_t st, const ParamSet& p, size_t n_xof_items, size_t n_prf_items, const uint8_t* rho, size_t rho_stride,
+                                int transpose, const uint8_t* r, int prf_per_item, int n_eta1, const Workspace& ws) {
     SampleArgs a{};
     a.n_xof = n_xof_items * (size_t)(p.k * p.k);
     a.rho = rho; a.rho_stride = rho_stride; a.K = p.k; a.transpose = transpose; a.A = ws.A;
@@ -209,23 +140,24 @@ inline void launch_sample_split(stream_t st, stream_t tail_st, const ParamSet& p
     a.prf_rate = ws.fips ? 136 : 168;
     zero_u32x2(st, ws.leftover);
     const size_t grid = a.xof_blocks + ceil_div(a.n_prf, WAVE);
-    if (grid != 0) {
-        if (ws.ring == 128) launch("k_sample_main", k_sample_main<128>, grid, WAVE, st, a);
-        else if (ws.ring == 32) launch("k_sample_main", k_sample_main<32>, grid, WAVE, st, a);
-        else if (ws.ring == 64) launch("k_sample_main", k_sample_main<64>, grid, WAVE, st, a);
-        else launch("k_sample_main", k_sample_main<0>, grid, WAVE, st, a);
-    }
-    if (pipe) tail_st = pipe->last_arith = pipe->arith_stream(buf);   // fork point: behind the three-block kernel
-    if (grid == 0 || a.n_xof == 0) return;
+    if (grid == 0) return;
+    launch("k_sample_main", k_sample_main, grid, WAVE, st, a);
+    if (a.n_xof == 0) return;
     // leftovers: expected 0.8 % of the sponges; the grids cover 1/16 of them and stride over the rest if ever needed.
     // First the sponges handed over with their state (one more permutation each), then the restart list (normally empty).
     SampleArgs t = a;
     t.list_mode = 1;
     t.n_prf = 0;
     t.xof_blocks = (unsigned)(ceil_div(a.n_xof, WAVE * 16) + 1);
-    if (a.resume_cap && ws.ring == 0) launch("k_sample_tail", k_sample_resume, (size_t)t.xof_blocks, WAVE, tail_st, t);
-    if (a.resume_cap && ws.ring == 0) t.xof_blocks = (unsigned)(ceil_div(a.n_xof, WAVE * 256) + 1);
-    launch("k_sample_restart", k_sample, (size_t)t.xof_blocks, WAVE, tail_st, t);
+    if (a.resume_cap) {
+        launch("k_sample_tail", k_sample_resume, (size_t)t.xof_blocks, WAVE, st, t);
+        t.xof_blocks = (unsigned)(ceil_div(a.n_xof, WAVE * 256) + 1);
+    }
+    launch("k_sample_restart", k_sample, (size_t)t.xof_blocks, WAVE, st, t);
+}
+inline void launch_sample(stream_t st, const ParamSet& p, size_t n, const uint8_t* rho, size_t rho_stride, int transpose,
+                          const uint8_t* r, int prf_per_item, int n_eta1, const Workspace& ws) {
+    launch_sample_split(st, p, n, n, rho, rho_stride, transpose, r, prf_per_item, n_eta1, ws);
 }
 
 // ---- ML-KEM.KeyGen_internal (ml_kem.c:1034-1084) ; z == nullptr: K-PKE.KeyGen alone (ml_kem.c:651-769, dk = 384k-byte ŝ) ----
@@ -237,23 +169,18 @@ inline void keygen_run(stream_t st, const ParamSet& p, size_t n, const uint8_t* 
     for (size_t h0 = 0; h0 < n; h0 += ws.hcap) {
         const size_t hn = min_sz(ws.hcap, n - h0);
         launch("k_hash_keygen_seed", k_hash_keygen_seed<K>, ceil_div(hn, WAVE), WAVE, st, hn, d + h0 * 32, ws.rho, ws.r);
-        ChunkPipe pipe(ws, st, ceil_div(hn, ws.cap));
         for (size_t c0 = 0; c0 < hn; c0 += ws.cap) {
             const size_t cn = min_sz(ws.cap, hn - c0), i0 = h0 + c0;
-            const int buf = pipe.begin_chunk();
-            const Workspace w = ws.view(buf);
-            const stream_t ast = launch_sample_piped(st, pipe, buf, p, cn, ws.rho + c0 * 32, 32, /*transpose=*/0, ws.r + c0 * 32, 2 * K, 2 * K, w);
+            launch_sample(st, p, cn, ws.rho + c0 * 32, 32, /*transpose=*/0, ws.r + c0 * 32, 2 * K, 2 * K, ws);
             if (kem)
-                launch("k_keygen", k_keygen<K, ETA1, true>, ceil_div(cn, ARITH_WAVES), WAVE * ARITH_WAVES, ast, cn,
-                       (const uint16_t*)w.A, (const uint8_t*)w.prf, (const uint8_t*)(ws.rho + c0 * 32), ek + i0 * p.ek_len,
+                launch("k_keygen", k_keygen<K, ETA1, true>, ceil_div(cn, ARITH_WAVES), WAVE * ARITH_WAVES, st, cn,
+                       (const uint16_t*)ws.A, (const uint8_t*)ws.prf, (const uint8_t*)(ws.rho + c0 * 32), ek + i0 * p.ek_len,
                        dk + i0 * dk_len);
             else
-                launch("k_keygen", k_keygen<K, ETA1, false>, ceil_div(cn, ARITH_WAVES), WAVE * ARITH_WAVES, ast, cn,
-                       (const uint16_t*)w.A, (const uint8_t*)w.prf, (const uint8_t*)(ws.rho + c0 * 32), ek + i0 * p.ek_len,
+                launch("k_keygen", k_keygen<K, ETA1, false>, ceil_div(cn, ARITH_WAVES), WAVE * ARITH_WAVES, st, cn,
+                       (const uint16_t*)ws.A, (const uint8_t*)ws.prf, (const uint8_t*)(ws.rho + c0 * 32), ek + i0 * p.ek_len,
                        dk + i0 * dk_len);
-            pipe.end_chunk(buf);
         }
-        pipe.join();
         if (kem)
             launch("k_hash_keygen_fin", k_hash_keygen_fin<K>, ceil_div(hn, WAVE), WAVE, st, hn, (const uint8_t*)(ek + h0 * p.ek_len),
                    z + h0 * 32, dk + h0 * p.dk_len);
@@ -270,20 +197,15 @@ inline void encaps_run(stream_t st, const ParamSet& p, size_t n, const uint8_t* 
         const uint8_t* r_h = r_user ? r_user + h0 * 32 : (const uint8_t*)ws.r;
         if (!r_user)
             launch("k_hash_encaps", k_hash_encaps<K>, ceil_div(hn, WAVE), WAVE, st, hn, ek + h0 * p.ek_len, m + h0 * 32, Kout + h0 * 32, ws.r);
-        ChunkPipe pipe(ws, st, ceil_div(hn, ws.cap));
         for (size_t c0 = 0; c0 < hn; c0 += ws.cap) {
             const size_t cn = min_sz(ws.cap, hn - c0), i0 = h0 + c0;
             const uint8_t* eki = ek + i0 * p.ek_len;
-            const int buf = pipe.begin_chunk();
-            const Workspace w = ws.view(buf);
-            const stream_t ast = launch_sample_piped(st, pipe, buf, p, cn, eki + 384 * K, p.ek_len, /*transpose=*/1, r_h + c0 * 32, 2 * K + 1, K, w);
+            launch_sample(st, p, cn, eki + 384 * K, p.ek_len, /*transpose=*/1, r_h + c0 * 32, 2 * K + 1, K, ws);
             launch("k_encrypt", k_encrypt<K, ETA1, DU, DV, false>, ceil_div(cn, ARITH_WAVES), WAVE * ARITH_WAVES,
-                   ast, cn, eki, (size_t)p.ek_len, m + i0 * 32, (const uint16_t*)w.A, (const uint8_t*)w.prf,
+                   st, cn, eki, (size_t)p.ek_len, m + i0 * 32, (const uint16_t*)ws.A, (const uint8_t*)ws.prf,
                    c + i0 * p.c_len, (const uint8_t*)nullptr, (const uint8_t*)nullptr, (const uint8_t*)nullptr, (uint8_t*)nullptr,
                    mod_status ? mod_status + i0 : (int32_t*)nullptr, (size_t)(K * K * 256));
-            pipe.end_chunk(buf);
         }
-        pipe.join();
     }
 }
 
@@ -315,20 +237,15 @@ inline void decaps_run(stream_t st, const ParamSet& p, size_t n, const uint8_t* 
             launch("k_hash_decaps", k_hash_decaps<K, CLEN, true, 136>, hgrid, WAVE, st, hn, dkh, ch, (const uint8_t*)ws.m, ws.Kp, ws.r, ws.Kbar, sth, (size_t)p.dk_len);
         else
             launch("k_hash_decaps", k_hash_decaps<K, CLEN, false, 136>, hgrid, WAVE, st, hn, dkh, ch, (const uint8_t*)ws.m, ws.Kp, ws.r, ws.Kbar, sth, (size_t)p.dk_len);
-        ChunkPipe pipe(ws, st, ceil_div(hn, ws.cap));
         for (size_t c0 = 0; c0 < hn; c0 += ws.cap) {
             const size_t cn = min_sz(ws.cap, hn - c0), i0 = h0 + c0;
             const uint8_t* dki = dk + i0 * p.dk_len;
-            const int buf = pipe.begin_chunk();
-            const Workspace w = ws.view(buf);
-            const stream_t ast = launch_sample_piped(st, pipe, buf, p, cn, dki + 768 * K, p.dk_len, /*transpose=*/1, ws.r + c0 * 32, 2 * K + 1, K, w);
+            launch_sample(st, p, cn, dki + 768 * K, p.dk_len, /*transpose=*/1, ws.r + c0 * 32, 2 * K + 1, K, ws);
             launch("k_encrypt_cmp", k_encrypt<K, ETA1, DU, DV, true>, ceil_div(cn, ARITH_WAVES), WAVE * ARITH_WAVES,
-                   ast, cn, dki + 384 * K, (size_t)p.dk_len, (const uint8_t*)(ws.m + c0 * 32), (const uint16_t*)w.A,
-                   (const uint8_t*)w.prf, (uint8_t*)nullptr, c + i0 * p.c_len, (const uint8_t*)(ws.Kp + c0 * 32),
+                   st, cn, dki + 384 * K, (size_t)p.dk_len, (const uint8_t*)(ws.m + c0 * 32), (const uint16_t*)ws.A,
+                   (const uint8_t*)ws.prf, (uint8_t*)nullptr, c + i0 * p.c_len, (const uint8_t*)(ws.Kp + c0 * 32),
                    (const uint8_t*)(ws.Kbar + c0 * 32), Kout + i0 * 32, (int32_t*)nullptr, (size_t)(K * K * 256));
-            pipe.end_chunk(buf);
         }
-        pipe.join();
     }
 }
 
@@ -338,16 +255,16 @@ inline void decaps_run(stream_t st, const ParamSet& p, size_t n, const uint8_t* 
 template <int K, int ETA1, int DU, int DV>
 inline void encaps_shared_run(stream_t st, const ParamSet& p, size_t n, const uint8_t* ek, const uint8_t* m, uint8_t* c, uint8_t* Kout,
                               const Workspace& ws) {
-    const Workspace w = ws.view(0);
+    const Workspace& w = ws;
     uint8_t* h = ws.rho;                                                          // 32 bytes, unused by Encaps otherwise
     launch("k_hash_batch", k_hash_batch<0>, (size_t)1, WAVE, st, (size_t)1, ek, (unsigned)p.ek_len, (size_t)p.ek_len, h);
-    launch_sample_split(st, st, p, 1, 0, ek + 384 * K, p.ek_len, /*transpose=*/1, nullptr, 0, 0, w);   // A^T once
+    launch_sample_split(st, p, 1, 0, ek + 384 * K, p.ek_len, /*transpose=*/1, nullptr, 0, 0, w);   // A^T once
     for (size_t h0 = 0; h0 < n; h0 += ws.hcap) {
         const size_t hn = min_sz(ws.hcap, n - h0);
         launch("k_hash_g_shared", k_hash_g_shared, ceil_div(hn, WAVE), WAVE, st, hn, m + h0 * 32, (const uint8_t*)h, Kout + h0 * 32, ws.r);
         for (size_t c0 = 0; c0 < hn; c0 += ws.cap) {
             const size_t cn = min_sz(ws.cap, hn - c0), i0 = h0 + c0;
-            launch_sample_split(st, st, p, 0, cn, nullptr, 0, 1, ws.r + c0 * 32, 2 * K + 1, K, w);      // PRF rows per item
+            launch_sample_split(st, p, 0, cn, nullptr, 0, 1, ws.r + c0 * 32, 2 * K + 1, K, w);      // PRF rows per item
             launch("k_encrypt", k_encrypt<K, ETA1, DU, DV, false>, ceil_div(cn, ARITH_WAVES), WAVE * ARITH_WAVES, st, cn, ek, (size_t)0,
                    m + i0 * 32, (const uint16_t*)w.A, (const uint8_t*)w.prf, c + i0 * p.c_len, (const uint8_t*)nullptr,
                    (const uint8_t*)nullptr, (const uint8_t*)nullptr, (uint8_t*)nullptr, (int32_t*)nullptr, (size_t)0);
@@ -358,12 +275,12 @@ template <int K, int ETA1, int DU, int DV>
 inline void decaps_shared_run(stream_t st, const ParamSet& p, size_t n, const uint8_t* dk, const uint8_t* c, uint8_t* Kout,
                               int32_t* status, const Workspace& ws) {
     constexpr int CLEN = 32 * (DU * K + DV);
-    const Workspace w = ws.view(0);
+    const Workspace& w = ws;
     if (status) {   // KEM_Decaps' hash check, once
         launch("k_hash_batch", k_hash_batch<0>, (size_t)1, WAVE, st, (size_t)1, dk + 384 * K, (unsigned)p.ek_len, (size_t)p.dk_len, ws.rho);
         launch("k_status_fill", k_status_fill, min_sz(ceil_div(n, 256), 1024), 256u, st, n, (const uint8_t*)ws.rho, dk + 768 * K + 32, status);
     }
-    launch_sample_split(st, st, p, 1, 0, dk + 768 * K, p.dk_len, /*transpose=*/1, nullptr, 0, 0, w);   // A^T once (rho sits in dk.ek)
+    launch_sample_split(st, p, 1, 0, dk + 768 * K, p.dk_len, /*transpose=*/1, nullptr, 0, 0, w);   // A^T once (rho sits in dk.ek)
     for (size_t h0 = 0; h0 < n; h0 += ws.hcap) {
         const size_t hn = min_sz(ws.hcap, n - h0);
         const uint8_t* ch = c + h0 * p.c_len;
@@ -375,7 +292,7 @@ inline void decaps_shared_run(stream_t st, const ParamSet& p, size_t n, const ui
             launch("k_hash_decaps", k_hash_decaps<K, CLEN, false, 136>, hgrid, WAVE, st, hn, dk, ch, (const uint8_t*)ws.m, ws.Kp, ws.r, ws.Kbar, (int32_t*)nullptr, (size_t)0);
         for (size_t c0 = 0; c0 < hn; c0 += ws.cap) {
             const size_t cn = min_sz(ws.cap, hn - c0), i0 = h0 + c0;
-            launch_sample_split(st, st, p, 0, cn, nullptr, 0, 1, ws.r + c0 * 32, 2 * K + 1, K, w);
+            launch_sample_split(st, p, 0, cn, nullptr, 0, 1, ws.r + c0 * 32, 2 * K + 1, K, w);
             launch("k_encrypt_cmp", k_encrypt<K, ETA1, DU, DV, true>, ceil_div(cn, ARITH_WAVES), WAVE * ARITH_WAVES, st, cn, dk + 384 * K,
                    (size_t)0, (const uint8_t*)(ws.m + c0 * 32), (const uint16_t*)w.A, (const uint8_t*)w.prf, (uint8_t*)nullptr, c + i0 * p.c_len,
                    (const uint8_t*)(ws.Kp + c0 * 32), (const uint8_t*)(ws.Kbar + c0 * 32), Kout + i0 * 32, (int32_t*)nullptr, (size_t)0);

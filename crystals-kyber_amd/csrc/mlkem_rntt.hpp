@@ -146,86 +146,123 @@ __device__ __forceinline__ void rntt_load_twiddles_inv(RnttTw& t) {
     t.c6 = a.idx6 ? -1.0f : 1.0f; t.c5 = a.idx5 ? -1.0f : 1.0f; t.c4 = a.idx4 ? -1.0f : 1.0f; t.c3 = a.idx3 ? -1.0f : 1.0f;
 }
 
-// register butterflies with the 3-FMA product (any twiddle, register or literal)
-__device__ __forceinline__ void ct_bfly_s(float& a, float& b, Tw zeta) {
-    const float t = fmulmod_shoup(zeta, b);
+// ---- packed fp32 ---------------------------------------------------------------------------------------------------------
+// idx0 is never a butterfly bit, so the coefficients 2i and 2i + 1 of a lane go through identical operations with identical
+// twiddles in every layer: modular products and register butterflies work on float2 pairs (v_pk_fma_f32 / v_pk_add_f32)
+// without any shuffle; only the DPP accumulate of the cross-lane layers has no packed form.  Against the scalar form of
+// round 2 (profiles/r03_kpke_experiments.txt, one box): k_ntt4_batch 614 -> 492 / 656 -> 525 VALU instructions and
+// -4.9 % / -5.5 % kernel time, k_decrypt4<3> 2723 -> 2180 and -9.4 %.  The library is built with -fno-slp-vectorize: where
+// pairs have to be FORMED (the LDS transforms of mlkem_fntt.hpp) packing costs more than it saves.
+#ifdef MLKEM_EMU
+struct v2f { float x, y; };
+__device__ __forceinline__ v2f operator+(v2f a, v2f b) { return v2f{a.x + b.x, a.y + b.y}; }
+__device__ __forceinline__ v2f operator-(v2f a, v2f b) { return v2f{a.x - b.x, a.y - b.y}; }
+__device__ __forceinline__ v2f fma2(v2f a, v2f b, v2f c) { return v2f{__builtin_fmaf(a.x, b.x, c.x), __builtin_fmaf(a.y, b.y, c.y)}; }
+#else
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f fma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+#endif
+__device__ __forceinline__ v2f splat2(float s) { return v2f{s, s}; }
+// zeta * b mod q on both halves: fmulmod_shoup (mlkem_fntt.hpp), |zeta b| <= 2^24, |result| <= 1668
+__device__ __forceinline__ v2f fmulmod_shoup2(Tw w, v2f b) {
+    const v2f km = fma2(b, splat2(w.zq), splat2(F_MAGIC));
+    const v2f nkq = fma2(km, splat2(-F_Q), splat2(F_MAGIC_Q));
+    return fma2(b, splat2(w.z), nkq);
+}
+__device__ __forceinline__ v2f fred2(v2f x) {
+    const v2f k = fma2(x, splat2(F_INVQ), splat2(F_MAGIC)) - splat2(F_MAGIC);
+    return fma2(k, splat2(-F_Q), x);
+}
+// register butterflies (any twiddle, register or literal)
+__device__ __forceinline__ void ct_bfly_p(v2f& a, v2f& b, Tw zeta) {
+    const v2f t = fmulmod_shoup2(zeta, b);
     b = a - t;
     a = a + t;
 }
-__device__ __forceinline__ void gs_bfly_s(float& a, float& b, Tw zeta) {
-    const float t = a;
+__device__ __forceinline__ void gs_bfly_p(v2f& a, v2f& b, Tw zeta) {
+    const v2f t = a;
     a = t + b;
-    b = fmulmod_shoup(zeta, b - t);
-}
-
-template <int XOR>
-__device__ __forceinline__ void ct_xlane(float (&lo)[8], float (&hi)[8], Tw e0, Tw e1, float c) {
-#pragma unroll
-    for (int i = 0; i < 8; i++) { lo[i] = fmulmod_shoup(e0, lo[i]); hi[i] = fmulmod_shoup(e1, hi[i]); }
-    xlane_fmac8<XOR>(lo, c);
-    xlane_fmac8<XOR>(hi, c);
+    b = fmulmod_shoup2(zeta, b - t);
 }
 template <int XOR>
-__device__ __forceinline__ void gs_xlane(float (&lo)[8], float (&hi)[8], Tw e0, Tw e1, float c) {
-    xlane_fmac8<XOR>(lo, c);
-    xlane_fmac8<XOR>(hi, c);
+__device__ __forceinline__ void xlane_fmac_p(v2f (&v)[4], float c) {
+    float t[8] = {v[0].x, v[0].y, v[1].x, v[1].y, v[2].x, v[2].y, v[3].x, v[3].y};   // the same registers: no moves
+    xlane_fmac8<XOR>(t, c);
+    v[0] = v2f{t[0], t[1]}; v[1] = v2f{t[2], t[3]}; v[2] = v2f{t[4], t[5]}; v[3] = v2f{t[6], t[7]};
+}
+template <int XOR>
+__device__ __forceinline__ void ct_xlane(v2f (&lo)[4], v2f (&hi)[4], Tw e0, Tw e1, float c) {
 #pragma unroll
-    for (int i = 0; i < 8; i++) { lo[i] = fmulmod_shoup(e0, lo[i]); hi[i] = fmulmod_shoup(e1, hi[i]); }
+    for (int i = 0; i < 4; i++) { lo[i] = fmulmod_shoup2(e0, lo[i]); hi[i] = fmulmod_shoup2(e1, hi[i]); }
+    xlane_fmac_p<XOR>(lo, c);
+    xlane_fmac_p<XOR>(hi, c);
+}
+template <int XOR>
+__device__ __forceinline__ void gs_xlane(v2f (&lo)[4], v2f (&hi)[4], Tw e0, Tw e1, float c) {
+    xlane_fmac_p<XOR>(lo, c);
+    xlane_fmac_p<XOR>(hi, c);
+#pragma unroll
+    for (int i = 0; i < 4; i++) { lo[i] = fmulmod_shoup2(e0, lo[i]); hi[i] = fmulmod_shoup2(e1, hi[i]); }
 }
 
-// Forward NTT of the wave's four polynomials.  In: lo[r] = coefficient 8 m + r, hi[r] = coefficient 128 + 8 m + r,
-// 0 <= x <= 4095.  Out: the same positions, |x| <= 6672 (lazy; canonicalise with fcanon_floor).
-__device__ __forceinline__ void wave4_ntt_r(float (&lo)[8], float (&hi)[8], const RnttTw& t) {
+// Forward NTT of the wave's four polynomials.  lo[i] = coefficients (8 m + 2 i, 8 m + 2 i + 1), hi[i] = the pair 128 further.
+// In: 0 <= x <= 4095.  Out: the same positions, |x| <= 6672 (lazy; canonicalise with fcanon_floor).
+__device__ __forceinline__ void wave4_ntt_p(v2f (&lo)[4], v2f (&hi)[4], const RnttTw& t) {
 #pragma unroll
-    for (int r = 0; r < 8; r++) ct_bfly_s(lo[r], hi[r], FZ1);                // len 128 : <= 4095 + 1668
+    for (int r = 0; r < 4; r++) ct_bfly_p(lo[r], hi[r], FZ1);               // len 128 : <= 4095 + 1668
     ct_xlane<XL_IDX6>(lo, hi, t.e6[0], t.e6[1], t.c6);                       // len 64  : multiplicand <= 5763, out <= 3336
     ct_xlane<XL_IDX5>(lo, hi, t.e5[0], t.e5[1], t.c5);                       // len 32
     ct_xlane<XL_IDX4>(lo, hi, t.e4[0], t.e4[1], t.c4);                       // len 16
     ct_xlane<XL_IDX3>(lo, hi, t.e3[0], t.e3[1], t.c3);                       // len 8   : <= 3336
 #pragma unroll
-    for (int r = 0; r < 4; r++) { ct_bfly_s(lo[r], lo[r + 4], t.z2[0]); ct_bfly_s(hi[r], hi[r + 4], t.z2[1]); }   // len 4 : <= 5004
-    ct_bfly_s(lo[0], lo[2], t.z1[0][0]); ct_bfly_s(lo[1], lo[3], t.z1[0][0]);                                    // len 2 : <= 6672
-    ct_bfly_s(lo[4], lo[6], t.z1[0][1]); ct_bfly_s(lo[5], lo[7], t.z1[0][1]);
-    ct_bfly_s(hi[0], hi[2], t.z1[1][0]); ct_bfly_s(hi[1], hi[3], t.z1[1][0]);
-    ct_bfly_s(hi[4], hi[6], t.z1[1][1]); ct_bfly_s(hi[5], hi[7], t.z1[1][1]);
+    for (int r = 0; r < 2; r++) { ct_bfly_p(lo[r], lo[r + 2], t.z2[0]); ct_bfly_p(hi[r], hi[r + 2], t.z2[1]); }   // len 4 : <= 5004
+    ct_bfly_p(lo[0], lo[1], t.z1[0][0]); ct_bfly_p(lo[2], lo[3], t.z1[0][1]);                                    // len 2 : <= 6672
+    ct_bfly_p(hi[0], hi[1], t.z1[1][0]); ct_bfly_p(hi[2], hi[3], t.z1[1][1]);
 }
-
 // Inverse NTT including the multiplication by 128^-1 (ml_kem.c:336-384).  In: 0 <= x <= 4095.  Out: |x| <= 1668.
-__device__ __forceinline__ void wave4_intt_r(float (&lo)[8], float (&hi)[8], const RnttTw& t) {
-    gs_bfly_s(lo[0], lo[2], t.z1[0][0]); gs_bfly_s(lo[1], lo[3], t.z1[0][0]);   // len 2 : sums <= 8190, products <= 1668
-    gs_bfly_s(lo[4], lo[6], t.z1[0][1]); gs_bfly_s(lo[5], lo[7], t.z1[0][1]);
-    gs_bfly_s(hi[0], hi[2], t.z1[1][0]); gs_bfly_s(hi[1], hi[3], t.z1[1][0]);
-    gs_bfly_s(hi[4], hi[6], t.z1[1][1]); gs_bfly_s(hi[5], hi[7], t.z1[1][1]);
+__device__ __forceinline__ void wave4_intt_p(v2f (&lo)[4], v2f (&hi)[4], const RnttTw& t) {
+    gs_bfly_p(lo[0], lo[1], t.z1[0][0]); gs_bfly_p(lo[2], lo[3], t.z1[0][1]);   // len 2 : sums <= 8190, products <= 1668
+    gs_bfly_p(hi[0], hi[1], t.z1[1][0]); gs_bfly_p(hi[2], hi[3], t.z1[1][1]);
 #pragma unroll
-    for (int r = 0; r < 4; r++) { gs_bfly_s(lo[r], lo[r + 4], t.z2[0]); gs_bfly_s(hi[r], hi[r + 4], t.z2[1]); }   // len 4 : multiplicand <= 9858
-    lo[0] = fred(lo[0]); lo[1] = fred(lo[1]); hi[0] = fred(hi[0]); hi[1] = fred(hi[1]);   // the sums of sums (<= 16380); the rest <= 3336
+    for (int r = 0; r < 2; r++) { gs_bfly_p(lo[r], lo[r + 2], t.z2[0]); gs_bfly_p(hi[r], hi[r + 2], t.z2[1]); }   // len 4 : multiplicand <= 9858
+    lo[0] = fred2(lo[0]); hi[0] = fred2(hi[0]);                              // the sums of sums (<= 16380); the rest <= 3336
     gs_xlane<XL_IDX3>(lo, hi, t.e3[0], t.e3[1], t.c3);                       // len 8  : |x +- x'| <= 6672, out <= 1668
     gs_xlane<XL_IDX4>(lo, hi, t.e4[0], t.e4[1], t.c4);                       // len 16
     gs_xlane<XL_IDX5>(lo, hi, t.e5[0], t.e5[1], t.c5);                       // len 32
     gs_xlane<XL_IDX6>(lo, hi, t.e6[0], t.e6[1], t.c6);                       // len 64
 #pragma unroll
-    for (int r = 0; r < 8; r++) {                                            // len 128 with the final scaling folded in:
-        const float s = lo[r] + hi[r], d = hi[r] - lo[r];                    //   a' = 128^-1 (a + b), b' = (zeta_1 128^-1)(b - a)
-        lo[r] = fmulmod_shoup(F_INV128, s);                                  //   |s|, |d| <= 3336
-        hi[r] = fmulmod_shoup(F_INV128_Z1, d);
+    for (int r = 0; r < 4; r++) {                                            // len 128 with the final scaling folded in:
+        const v2f sm = lo[r] + hi[r], d = hi[r] - lo[r];                     //   a' = 128^-1 (a + b), b' = (zeta_1 128^-1)(b - a)
+        lo[r] = fmulmod_shoup2(F_INV128, sm);                                //   |s|, |d| <= 3336
+        hi[r] = fmulmod_shoup2(F_INV128_Z1, d);
     }
 }
+// float[8] views (lo[r] = coefficient 8 m + r, hi[r] = coefficient 128 + 8 m + r): what the codecs around the transforms use
+#define MLKEM_V2F_IN(l, h, lo, hi)                                                                              \
+    v2f l[4] = {v2f{lo[0], lo[1]}, v2f{lo[2], lo[3]}, v2f{lo[4], lo[5]}, v2f{lo[6], lo[7]}};                    \
+    v2f h[4] = {v2f{hi[0], hi[1]}, v2f{hi[2], hi[3]}, v2f{hi[4], hi[5]}, v2f{hi[6], hi[7]}};
+#define MLKEM_V2F_OUT(l, h, lo, hi)                                                                             \
+    _Pragma("unroll") for (int i = 0; i < 4; i++) { lo[2 * i] = l[i].x; lo[2 * i + 1] = l[i].y; hi[2 * i] = h[i].x; hi[2 * i + 1] = h[i].y; }
+__device__ __forceinline__ void wave4_ntt_r(float (&lo)[8], float (&hi)[8], const RnttTw& t) {
+    MLKEM_V2F_IN(l, h, lo, hi)
+    wave4_ntt_p(l, h, t);
+    MLKEM_V2F_OUT(l, h, lo, hi)
+}
+__device__ __forceinline__ void wave4_intt_r(float (&lo)[8], float (&hi)[8], const RnttTw& t) {
+    MLKEM_V2F_IN(l, h, lo, hi)
+    wave4_intt_p(l, h, t);
+    MLKEM_V2F_OUT(l, h, lo, hi)
+}
+#undef MLKEM_V2F_IN
+#undef MLKEM_V2F_OUT
 
-#ifndef MLKEM_RNTT_SDWA
-#define MLKEM_RNTT_SDWA 0   // 1: v_cvt_f32_u32_sdwa picks its 16-bit half (3 instead of 4 instructions per dword) -- measured 4 % SLOWER
-#endif                      //    (0.221 against 0.213 ms per 2^20 polynomials, alternating runs on one box), so the plain form stays
 // 8 coefficients (16 bytes) <-> registers; inputs are taken mod 2^12 like the reference's 12-bit `union integer.t`
 __device__ __forceinline__ void rntt_unpack(const uint4 v, float (&x)[8]) {
     const uint32_t w[4] = {v.x & 0x0FFF0FFFu, v.y & 0x0FFF0FFFu, v.z & 0x0FFF0FFFu, v.w & 0x0FFF0FFFu};
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-#if defined(MLKEM_EMU) || !MLKEM_RNTT_SDWA
-        x[2 * i] = (float)(w[i] & 0xFFFFu);
+        x[2 * i] = (float)(w[i] & 0xFFFFu);      // (an SDWA conversion that picks its 16-bit half was measured 4 % slower)
         x[2 * i + 1] = (float)(w[i] >> 16);
-#else   // one mask per dword, then the conversion selects its 16-bit half itself (SDWA): 3 instructions per 2 coefficients, not 4
-        asm("v_cvt_f32_u32_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0" : "=v"(x[2 * i]) : "v"(w[i]));
-        asm("v_cvt_f32_u32_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "=v"(x[2 * i + 1]) : "v"(w[i]));
-#endif
     }
 }
 __device__ __forceinline__ uint4 rntt_pack_canonical(const float (&x)[8]) {

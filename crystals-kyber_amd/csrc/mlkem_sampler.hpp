@@ -1,144 +1,22 @@
 // mlkem_sampler.hpp — the fast path of SampleNTT / PRF sampling (ml_kem.c:189-245, :496-515).
 //
 // k_sample_main : every XOF lane squeezes exactly THREE SHAKE128 blocks (336 candidates, mean 273 accepted);
-//                 the ~0.8 % of sponges that still miss coefficients are appended to a leftover list and
-//                 finished by the general kernel k_sample (mlkem_kernels.hpp) in a second, tiny launch.  Without
-//                 this split ~40 % of the waves would run a 4th permutation for the sake of one or two lanes.
+//                 the ~0.8 % of sponges that still miss coefficients are handed over with their Keccak state and
+//                 finished by k_sample_resume (one more permutation) in a second, tiny launch.  Without this split
+//                 ~40 % of the waves would run a 4th permutation for the sake of one or two lanes.
 //                 Blocks 0 and 1 can never complete a polynomial (2 x 112 < 256), so their rejection loop
-//                 carries no `count < 256` test and writes unconditionally (rejected values are overwritten).
-//                 The per-lane LDS ring holds RING coefficients and is flushed in aligned RING/2-coefficient
-//                 chunks at NFLUSH points per block (RING = 64: 9 KB per wave, 64-byte chunks, 4 lanes x 16 B).
+//                 carries no `count < 256` test.
 //                 PRF lanes: one permutation (two for eta = 3), raw bytes out.
+// Earlier forms of the staging (per-lane LDS rings of 32 / 64 / 128 coefficients, cooperative flushes) are in the git
+// history and their measurements in profiles/r01_*, profiles/r02_sampler_experiments.txt.
 #pragma once
 #include "mlkem_kernels.hpp"
 
 namespace mlkem {
 
-template <int RING_N>
-struct RingCfg {
-    static constexpr int N = RING_N;                 // coefficients per lane ring (power of two)
-    static constexpr int CHUNK = RING_N / 2;         // coefficients per flushed chunk
-    static constexpr int STRIDE = RING_N + 8;        // int16 per row (16-byte aligned rows, skewed banks)
-    static constexpr int LPC = CHUNK / 8;            // lanes per chunk (16 B each)
-    static constexpr int PPS = WAVE / LPC;           // polynomials per flush step
-    static constexpr int STEPS = WAVE / PPS;         // flush steps to cover the 64 lanes
-};
-
-// flush every completed chunk (at most one per lane per call)
-template <class R>
-__device__ __forceinline__ void ring_flush_t(const int16_t* ring, uint16_t* A, size_t g, size_t n_xof, int cnt, int& flushed) {
-    const int l = lane_id();
-    const int has = (cnt - flushed >= R::CHUNK) && (g < n_xof);
-    if (__ballot(has) == 0) return;
-    const int grp = l / R::LPC, sub = l % R::LPC;
-#pragma unroll 1
-    for (int step = 0; step < R::STEPS; step++) {
-        const int p = step * R::PPS + grp;
-        const int p_has = __shfl(has, p);
-        const int p_flushed = __shfl(flushed, p);
-        if (p_has) {
-            const int16_t* src = ring + p * R::STRIDE + (p_flushed & (R::N - 1)) + sub * 8;
-            const uint4 v = *reinterpret_cast<const uint4*>(src);
-            const size_t gp = g - (size_t)l + (size_t)p;
-            *reinterpret_cast<uint4*>(A + gp * 256 + p_flushed + sub * 8) = v;
-        }
-    }
-    if (has) flushed += R::CHUNK;
-}
-
-// one 3-byte group -> two candidates (ml_kem.c:208-219).  `pos` = 2 x (number of accepted coefficients): the ring is
-// addressed in bytes so that accepting costs v_cmp + v_cndmask(0, 2) + one full-rate v_add (an element index would add
-// a slow-class v_lshl_add per candidate for the address).
-#define MLKEM_RING_AT(p) (*reinterpret_cast<int16_t*>(ringb + ((p) & (2u * R::N - 1u))))
-#define MLKEM_T_FAST(v)                                                                   \
-    {                                                                                     \
-        const uint32_t d1 = (v) & 0xFFFu, d2 = (v) >> 12;                                 \
-        MLKEM_RING_AT(pos) = (int16_t)d1; pos += d1 < (uint32_t)KQ ? 2u : 0u;             \
-        MLKEM_RING_AT(pos) = (int16_t)d2; pos += d2 < (uint32_t)KQ ? 2u : 0u;             \
-    }
-#define MLKEM_T_GUARD(v)                                                                  \
-    {                                                                                     \
-        const uint32_t d1 = (v) & 0xFFFu, d2 = (v) >> 12;                                 \
-        if (d1 < (uint32_t)KQ && pos < 512u) { MLKEM_RING_AT(pos) = (int16_t)d1; pos += 2u; } \
-        if (d2 < (uint32_t)KQ && pos < 512u) { MLKEM_RING_AT(pos) = (int16_t)d2; pos += 2u; } \
-    }
-// triples FIRST..LAST-1 (0..3) of the 12-byte group starting at state dword W0
-#define MLKEM_G(T, W0, FIRST, LAST)                                                                       \
-    {                                                                                                     \
-        const uint32_t w0 = keccak_word<W0>(s), w1 = keccak_word<W0 + 1>(s), w2 = keccak_word<W0 + 2>(s); \
-        if (FIRST <= 0 && LAST > 0) T(w0 & 0xFFFFFFu)                                                     \
-        if (FIRST <= 1 && LAST > 1) T((w0 >> 24) | ((w1 & 0xFFFFu) << 8))                                 \
-        if (FIRST <= 2 && LAST > 2) T((w1 >> 16) | ((w2 & 0xFFu) << 16))                                  \
-        if (FIRST <= 3 && LAST > 3) T(w2 >> 8)                                                            \
-    }
-// Own-lane flush: every lane copies its own completed chunk (CHUNK/8 x ds_read_b128 + global_store_dwordx4).  No
-// cross-lane traffic, no fences; the scattered 16-byte stores (one 64-byte segment per lane, completed by consecutive
-// instructions) ride on the otherwise idle memory pipe, whereas the cooperative variant above spends ~45 VALU/DS
-// instructions per flush point in a VALU-bound kernel.  MLKEM_SAMPLER_COOP_FLUSH=1 selects the cooperative variant.
-#ifndef MLKEM_EXP_A384
-#define MLKEM_EXP_A384 0
-#endif
-#ifndef MLKEM_SAMPLER_COOP_FLUSH
-#define MLKEM_SAMPLER_COOP_FLUSH 0
-#endif
-template <class R>
-__device__ __forceinline__ void ring_flush_own(const char* ringb, uint16_t* A, size_t g, size_t n_xof, uint32_t pos, uint32_t& flushed) {
-    // pos / flushed in bytes (2 per coefficient)
-    if ((pos - flushed >= 2u * R::CHUNK) && (g < n_xof)) {
-        const char* src = ringb + (flushed & (2u * R::N - 1u));
-        char* dst = reinterpret_cast<char*>(A + g * 256) + flushed;
-#if MLKEM_EXP_A384   // TIMING EXPERIMENT ONLY (wrong results): 384 instead of 512 bytes per polynomial reach HBM, the upper
-        if (flushed < 384u)   // bound of what a 12-bit packed matrix could save (no pack / unpack instructions are paid here)
-#endif
-#pragma unroll
-        for (int q = 0; q < R::CHUNK / 8; q++)
-            reinterpret_cast<uint4*>(dst)[q] = reinterpret_cast<const uint4*>(src)[q];
-        flushed += 2u * R::CHUNK;
-    }
-}
-#if MLKEM_SAMPLER_COOP_FLUSH
-#define MLKEM_FLUSH()                                                       \
-    {                                                                       \
-        int fl = (int)(flushed >> 1);                                       \
-        wave_lds_fence();                                                   \
-        ring_flush_t<R>(ring, a.A, g, a.n_xof, (int)(pos >> 1), fl);        \
-        wave_lds_fence();                                                   \
-        flushed = (uint32_t)fl << 1;                                        \
-    }
-#else
-#define MLKEM_FLUSH() ring_flush_own<R>(ringb, a.A, g, a.n_xof, pos, flushed);
-#endif
-
-// the 56 triples of one squeezed block, with NFLUSH = 4 (quarters of 14 triples) or 2 (halves of 28) flush points
-#define MLKEM_BLOCK(T)                                                                                      \
-    MLKEM_G(T, 0, 0, 4) MLKEM_G(T, 3, 0, 4) MLKEM_G(T, 6, 0, 4) MLKEM_G(T, 9, 0, 2)                         \
-    if (R::N < 128) { MLKEM_FLUSH() }                                                                       \
-    MLKEM_G(T, 9, 2, 4) MLKEM_G(T, 12, 0, 4) MLKEM_G(T, 15, 0, 4) MLKEM_G(T, 18, 0, 4)                      \
-    MLKEM_FLUSH()                                                                                           \
-    MLKEM_G(T, 21, 0, 4) MLKEM_G(T, 24, 0, 4) MLKEM_G(T, 27, 0, 4) MLKEM_G(T, 30, 0, 2)                     \
-    if (R::N < 128) { MLKEM_FLUSH() }                                                                       \
-    MLKEM_G(T, 30, 2, 4) MLKEM_G(T, 33, 0, 4) MLKEM_G(T, 36, 0, 4) MLKEM_G(T, 39, 0, 4)                     \
-    MLKEM_FLUSH()
-
-// RING = 32: a flush point after every 8 triples (16 candidates): at most 15 coefficients are pending after a flush
-// point, so the 32-slot ring never wraps onto unflushed data.  5 KB of LDS per wave instead of 9 KB.
-#define MLKEM_BLOCK32(T)                                                        \
-    MLKEM_G(T, 0, 0, 4) MLKEM_G(T, 3, 0, 4) MLKEM_FLUSH()                       \
-    MLKEM_G(T, 6, 0, 4) MLKEM_G(T, 9, 0, 4) MLKEM_FLUSH()                       \
-    MLKEM_G(T, 12, 0, 4) MLKEM_G(T, 15, 0, 4) MLKEM_FLUSH()                     \
-    MLKEM_G(T, 18, 0, 4) MLKEM_G(T, 21, 0, 4) MLKEM_FLUSH()                     \
-    MLKEM_G(T, 24, 0, 4) MLKEM_G(T, 27, 0, 4) MLKEM_FLUSH()                     \
-    MLKEM_G(T, 30, 0, 4) MLKEM_G(T, 33, 0, 4) MLKEM_FLUSH()                     \
-    MLKEM_G(T, 36, 0, 4) MLKEM_G(T, 39, 0, 4) MLKEM_FLUSH()
-#define MLKEM_SQUEEZE(T)                                  \
-    if constexpr (R::N == 32) { MLKEM_BLOCK32(T) }        \
-    else { MLKEM_BLOCK(T) }
-
-// ---- RING_N = 0: linear staging buffer + EXEC-masked acceptance (the default) ----------------------------------------
-// The ring above pays v_cmp + v_cndmask + v_add for the position and v_and + v_add for the wrapped address of every one
-// of the 336 candidates (7.2 issue units each, 15 % of the permutation's).  Here a lane's `pos` IS the LDS byte address of
-// its next coefficient in a linear 144-byte buffer, and a candidate is accepted by masking: v_cmpx_gt_u32 leaves EXEC =
-// lanes whose candidate is < q, the ds_write_b16 and the v_add_u32 pos += 2 run under that mask, s_mov_b64 restores EXEC
+// ---- linear staging buffer + EXEC-masked acceptance --------------------------------------------------------------------
+// A lane's `pos` IS the LDS byte address of its next coefficient in a linear 144-byte buffer, and a candidate is accepted
+// by masking: v_cmpx_gt_u32 leaves EXEC = lanes whose candidate is < q, the ds_write_b16 and the v_add_u32 pos += 2 run under that mask, s_mov_b64 restores EXEC
 // (4.3 units: one VOPC + one plain VALU; the DS and scalar instructions issue on their own ports).  Twice per block the
 // complete 32-byte pieces go to HBM and the < 32-byte remainder moves to the front of the buffer (at most 30 + 112 bytes
 // are ever staged: 56 candidates between flush points).
@@ -206,11 +84,9 @@ __device__ __forceinline__ void lin_flush(char* buf, uint32_t pos0, uint32_t& po
     flushed += 32u * n32;
 }
 
-template <int RING_N>
-__global__ void __launch_bounds__(WAVE, (RING_N == 32 ? MLKEM_KECCAK_MINWAVES : RING_N == 128 ? 2 : 4)) k_sample_main(SampleArgs a) {   // LDS caps rings 0 / 64 / 128 at 4 / 4 / 2 waves per SIMD
-    using R = RingCfg<RING_N == 0 ? 64 : RING_N>;
-    static_assert(WAVE * R::STRIDE * 2 >= 32 * 33 * 4 && (RING_N != 0 || R::STRIDE * 2 >= LIN_STRIDE), "the PRF role stages 32 rows x 33 dwords in the ring");
-    __shared__ __attribute__((aligned(16))) int16_t ring[WAVE * R::STRIDE];
+__global__ void __launch_bounds__(WAVE, 4) k_sample_main(SampleArgs a) {   // 9 KB of LDS per wave: 4 waves per SIMD
+    static_assert(WAVE * LIN_STRIDE >= 32 * 33 * 4, "the PRF role stages 32 rows x 33 dwords in the same buffer");
+    __shared__ __attribute__((aligned(16))) char stage[WAVE * LIN_STRIDE];
     const int l = lane_id();
     KeccakState s;
     if (blockIdx.x < a.xof_blocks) {
@@ -222,7 +98,6 @@ __global__ void __launch_bounds__(WAVE, (RING_N == 32 ? MLKEM_KECCAK_MINWAVES : 
         const unsigned e = (unsigned)(gc - item * kk), ra = e / (unsigned)a.K, cb = e - ra * (unsigned)a.K;
         load32(a.rho, a.rho_stride, item, seed);
         const unsigned i0 = a.transpose ? ra : cb, i1 = a.transpose ? cb : ra;
-        char* ringb = reinterpret_cast<char*>(ring + l * R::STRIDE);   // this lane's ring / staging buffer
         keccak_zero(s);
         MLKEM_SET_WORDS8(s, 0, seed)
         keccak_xor_byte<32>(s, i0);
@@ -231,8 +106,8 @@ __global__ void __launch_bounds__(WAVE, (RING_N == 32 ? MLKEM_KECCAK_MINWAVES : 
         keccak_xor_byte<167>(s, 0x80);
         bool unfinished;
         uint32_t resume_cnt = 0;   // coefficients of this polynomial already in HBM when the sponge is handed over
-        if constexpr (RING_N == 0) {
-            char* lbuf = reinterpret_cast<char*>(ring) + l * LIN_STRIDE;
+        {
+            char* lbuf = stage + l * LIN_STRIDE;   // this lane's staging buffer
 #ifdef MLKEM_EMU
             char* const lds0 = lbuf;                 // emulator: positions are offsets into the lane's own buffer
             const uint32_t pos0 = 0;
@@ -260,19 +135,9 @@ __global__ void __launch_bounds__(WAVE, (RING_N == 32 ? MLKEM_KECCAK_MINWAVES : 
                 *reinterpret_cast<uint4*>(dst_poly + flushed + 16u) = *reinterpret_cast<const uint4*>(lbuf + 16);
             }
             resume_cnt = (flushed + (pos - pos0)) >> 1;
-        } else {
-            uint32_t pos = 0, flushed = 0;                                 // bytes: 2 x accepted / flushed coefficients
-            keccak_f1600(s);
-            MLKEM_SQUEEZE(MLKEM_T_FAST)
-            keccak_f1600(s);
-            MLKEM_SQUEEZE(MLKEM_T_FAST)
-            keccak_f1600(s);
-            MLKEM_SQUEEZE(MLKEM_T_GUARD)
-            unfinished = pos < 512u;
         }
         if (unfinished && g < a.n_xof) {   // ~0.8 % of sponges: finished by the leftover passes
-            uint32_t idx = a.resume_cap;
-            if constexpr (RING_N == 0) idx = atomicAdd(&a.leftover[1], 1u);
+            const uint32_t idx = atomicAdd(&a.leftover[1], 1u);
             if (idx < a.resume_cap) {   // hand over the sponge as it stands: the fourth block costs one permutation there, not four
                 uint32_t* e = a.resume + (size_t)idx * RESUME_WORDS;
                 e[0] = (uint32_t)g;
@@ -307,7 +172,7 @@ __global__ void __launch_bounds__(WAVE, (RING_N == 32 ? MLKEM_KECCAK_MINWAVES : 
         keccak_f1600(s);
         // stage the first 128 bytes of every lane in LDS, 32 lanes at a time (32 rows x 33 dwords: odd stride,
         // conflict-free, 4.2 KB), and write them out as 16 B per lane, 8 lanes per row
-        uint32_t* st32 = reinterpret_cast<uint32_t*>(ring);
+        uint32_t* st32 = reinterpret_cast<uint32_t*>(stage);
         const size_t g0 = g - (size_t)l;
 #pragma unroll 1
         for (int half = 0; half < 2; half++) {

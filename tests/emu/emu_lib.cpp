@@ -1,6 +1,6 @@
 // tests/emu/emu_lib.cpp — TEST INFRASTRUCTURE ONLY: the product's kernels + pipeline compiled for the
 // host wave emulator (hip_emu.hpp) and exported with the same call shapes as the C-ABI device entry points.
-// `cap`/`hcap`/`ring` let the tests exercise the chunk / h-chunk loops and both sampler ring sizes.
+// `cap`/`hcap` let the tests exercise the chunk / h-chunk loops.
 #include "hip_emu.hpp"
 
 #include "../../crystals-kyber_amd/csrc/mlkem_pipeline.hpp"
@@ -10,7 +10,7 @@
 using namespace mlkem;
 
 static size_t g_cap = 0, g_hcap = 0;
-static int g_ring = 0, g_fips = 0;
+static int g_fips = 0;
 static int g_resume_cap = 64;   // resume records per chunk; a small value exercises the overflow into the restart list
 
 static void* xalloc(size_t bytes) { return aligned_alloc(64, (bytes + 127) / 64 * 64); }
@@ -20,16 +20,12 @@ static Workspace make_ws(size_t n) {
     ws.cap = g_cap ? g_cap : (n ? n : 1);
     ws.hcap = g_hcap ? g_hcap : (n ? n : 1);
     if (ws.hcap < ws.cap) ws.hcap = ws.cap;
-    ws.ring = g_ring;
     ws.fips = g_fips;
-    for (int b = 0; b < 2; b++) {
-        ws.A2[b] = (uint16_t*)xalloc(ws.cap * 16 * 512);
-        ws.prf2[b] = (uint8_t*)xalloc(ws.cap * 9 * 192);
-        ws.leftover2[b] = (uint32_t*)xalloc((ws.cap * 16 + 2) * 4);
-        ws.resume2[b] = (uint32_t*)xalloc((size_t)g_resume_cap * RESUME_WORDS * 4 + 16);
-    }
+    ws.A = (uint16_t*)xalloc(ws.cap * 16 * 512);
+    ws.prf = (uint8_t*)xalloc(ws.cap * 9 * 192);
+    ws.leftover = (uint32_t*)xalloc((ws.cap * 16 + 2) * 4);
+    ws.resume = (uint32_t*)xalloc((size_t)g_resume_cap * RESUME_WORDS * 4 + 16);
     ws.resume_cap = (uint32_t)g_resume_cap;
-    ws.A = ws.A2[0]; ws.prf = ws.prf2[0]; ws.leftover = ws.leftover2[0]; ws.resume = ws.resume2[0];
     ws.r = (uint8_t*)xalloc(ws.hcap * 32);
     ws.rho = (uint8_t*)xalloc(ws.hcap * 32);
     ws.m = (uint8_t*)xalloc(ws.hcap * 32);
@@ -38,7 +34,7 @@ static Workspace make_ws(size_t n) {
     return ws;
 }
 static void free_ws(Workspace& ws) {
-    for (int b = 0; b < 2; b++) { free(ws.A2[b]); free(ws.prf2[b]); free(ws.leftover2[b]); free(ws.resume2[b]); }
+    free(ws.A); free(ws.prf); free(ws.leftover); free(ws.resume);
     free(ws.r); free(ws.rho); free(ws.m); free(ws.Kp); free(ws.Kbar);
 }
 
@@ -55,7 +51,7 @@ static long compress_f_mismatches() {
 }
 
 extern "C" {
-void emu_config(size_t cap, size_t hcap, int ring) { g_cap = cap; g_hcap = hcap; g_ring = (ring == 128 || ring == 64 || ring == 32) ? ring : 0; }
+void emu_config(size_t cap, size_t hcap) { g_cap = cap; g_hcap = hcap; }
 void emu_conformance(int fips) { g_fips = fips != 0; }
 void emu_resume_cap(int cap) { g_resume_cap = cap < 0 ? 0 : cap; }
 int emu_keygen(int set, size_t n, const uint8_t* d, const uint8_t* z, uint8_t* ek, uint8_t* dk) {
@@ -129,11 +125,10 @@ int emu_sample_matrix(int k, size_t n, const uint8_t* rho, int transpose, uint16
     param_set(k == 2 ? 512 : k == 3 ? 768 : 1024, p);
     uint8_t* r = (uint8_t*)xalloc(n * 32);
     for (size_t i = 0; i < n * 32; i++) r[i] = (uint8_t)i;
-    launch_sample(nullptr, p, n, rho, 32, transpose, r, 2 * k + 1, k, ws.view(0));
+    launch_sample(nullptr, p, n, rho, 32, transpose, r, 2 * k + 1, k, ws);
     memcpy(A_out, ws.A, n * (size_t)(k * k) * 512);
-    // low half: sponges that needed a 4th block (leftover[1] counts every hand-over attempt of the linear form; the ring forms
-    // only know the restart list); high half: restarts from the seed
-    int left = (int)(ws.leftover[1] ? ws.leftover[1] : ws.leftover[0]) | ((int)ws.leftover[0] << 16);
+    // low half: sponges that needed a 4th block (leftover[1] counts every hand-over attempt); high half: restarts from the seed
+    int left = (int)ws.leftover[1] | ((int)ws.leftover[0] << 16);
     free(r);
     free_ws(ws);
     return left;

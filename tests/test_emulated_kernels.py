@@ -156,7 +156,7 @@ def test_emu_codec_primitives(emu, oracle, golden_npz, d):
 def test_emu_shared_key_batches(emu, oracle, pset):
     """One key for the whole batch: same bytes as the per-item path on the replicated key (oracle), incl. implicit
     rejection and the once-per-call dk hash check; chunk loops crossed (cap 3, hcap 7, 17 items)."""
-    emu.emu_config(C.c_size_t(3), C.c_size_t(7), 0)
+    emu.emu_config(C.c_size_t(3), C.c_size_t(7))
     try:
         ekl, dkl, cl = SIZES[pset]
         n = 17
@@ -177,7 +177,7 @@ def test_emu_shared_key_batches(emu, oracle, pset):
         assert emu.emu_decaps_shared(pset, C.c_size_t(n), p8(dkb), p8(cb), p8(Kd), st.ctypes.data_as(C.POINTER(C.c_int32))) == 0
         assert (st == -5).all()
     finally:
-        emu.emu_config(C.c_size_t(0), C.c_size_t(0), 0)
+        emu.emu_config(C.c_size_t(0), C.c_size_t(0))
 
 
 @pytest.mark.parametrize("pset", (512, 768, 1024))
@@ -247,26 +247,22 @@ def test_emu_full_wave_hash_kernels_take_the_dma_staging(emu, oracle, pset):
         assert not (Kd[i] == K[i]).all()
 
 
-@pytest.mark.parametrize("ring,resume_cap", ((0, 64), (0, 2), (0, 0), (32, 64), (64, 64), (128, 64)))
-def test_emu_matrix_sampler_with_leftover_pass(emu, oracle, ring, resume_cap):
+@pytest.mark.parametrize("resume_cap", (64, 2, 0))
+def test_emu_matrix_sampler_with_leftover_pass(emu, oracle, resume_cap):
     """Production SampleNTT path: three-block main kernel + the leftover passes.  With 576 sponges about 0.8 % (4-5) need
-    a 4th squeeze block; the test requires that the leftover path was taken.  ring 0 (default) = linear staging buffer,
-    leftovers handed over with their sponge state (k_sample_resume); a small resume capacity pushes the overflow (or, with
-    capacity 0, everything) onto the restart list that k_sample redoes from the seed, as the ring forms always do."""
-    emu.emu_config(C.c_size_t(0), C.c_size_t(0), ring)
+    a 4th squeeze block; the test requires that the leftover path was taken.  Leftovers are handed over with their sponge
+    state (k_sample_resume); a small resume capacity pushes the overflow (or, with capacity 0, everything) onto the restart
+    list that k_sample redoes from the seed."""
+    emu.emu_config(C.c_size_t(0), C.c_size_t(0))
     emu.emu_resume_cap(resume_cap)
     k, n = 3, 64
-    rho = seeds("emu-rho", n, 31 + ring)
+    rho = seeds("emu-rho", n, 31)
     A = np.zeros((n, k * k, 256), np.uint16)
     left = emu.emu_sample_matrix(k, C.c_size_t(n), p8(rho), 1, p16(A))
-    emu.emu_config(C.c_size_t(0), C.c_size_t(0), 0)
     emu.emu_resume_cap(64)
     total, restarted = left & 0xFFFF, left >> 16
     assert total >= 2, "seed set must exercise the leftover passes"
-    if ring == 0:
-        assert restarted == max(0, total - resume_cap), (total, restarted)    # records beyond the capacity restart from the seed
-    else:
-        assert restarted == total
+    assert restarted == max(0, total - resume_cap), (total, restarted)    # records beyond the capacity restart from the seed
     for i in range(n):
         for a in range(k):
             for b in range(k):
@@ -277,7 +273,7 @@ def test_emu_matrix_sampler_with_leftover_pass(emu, oracle, ring, resume_cap):
 
 def test_emu_chunk_and_hchunk_loops(emu, oracle):
     """cap = 3 items per chunk, hcap = 7 items per h-chunk, 17 items: every loop boundary is crossed."""
-    emu.emu_config(C.c_size_t(3), C.c_size_t(7), 0)
+    emu.emu_config(C.c_size_t(3), C.c_size_t(7))
     try:
         pset, n = 768, 17
         ekl, dkl, cl = SIZES[pset]
@@ -297,7 +293,7 @@ def test_emu_chunk_and_hchunk_loops(emu, oracle):
         Ko, sto = oracle.decaps(pset, dk, cb)
         assert (st == 0).all() and (sto == 0).all() and (Kd == Ko).all()
     finally:
-        emu.emu_config(C.c_size_t(0), C.c_size_t(0), 0)
+        emu.emu_config(C.c_size_t(0), C.c_size_t(0))
 
 
 def test_emu_raw_sponge_nist_examples_and_bit_lengths(emu, oracle, golden):

@@ -538,13 +538,12 @@ def test_reference_primitive_symbols_through_the_shim(pkg, tmp_path, golden, gol
     assert "eta must be 2 or 3" in r.stderr and "Test Complete!" in r.stdout
 
 
-@pytest.mark.parametrize("env", ({"MLKEM_OVERLAP": "1"}, {"MLKEM_RING": "128"}, {"MLKEM_RING": "64"}, {"MLKEM_RING": "32"}, {"MLKEM_HCHUNK_ITEMS": "300"}))
+@pytest.mark.parametrize("env", ({"MLKEM_HCHUNK_ITEMS": "300"}, {"MLKEM_CHUNK_ITEMS": "77", "MLKEM_HCHUNK_ITEMS": "154"}))
 def test_engine_options_do_not_change_results(pkg, torch, oracle, env, monkeypatch):
-    """Opt-in execution modes read at context creation: two-stream sampler/arithmetic overlap, the 128-coefficient
-    sampler ring, small h-chunks.  Same bytes out."""
+    """The two sizing knobs read at context creation (chunk and h-chunk capacity): same bytes out."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
-    e = pkg.MLKEM(768, device=0, chunk_items=128)     # several chunks (and h-chunks) per call
+    e = pkg.MLKEM(768, device=0, chunk_items=0 if "MLKEM_CHUNK_ITEMS" in env else 128)     # several chunks (and h-chunks) per call
     n = 700
     d, z, m = seeds("opt-d", n, 3), seeds("opt-z", n, 3), seeds("opt-m", n, 3)
     ek, dk = e.keygen(dev(torch, d), dev(torch, z))
