@@ -581,8 +581,8 @@ def entry(workload, args, elapsed, ok, extra, world):
             roofline["traffic"] = t["hbm_bytes_per_step_corrected"]
             roofline["traffic_note"] = "bytes per STEP (all kernels) from %s (git %s, source_id %s): (2*FETCH_SIZE + WRITE_SIZE)*1024; raw = %.3g" % (
                 os.path.relpath(tpath, ROOT), t.get("git_head", "?"), t["source_id"], t["hbm_bytes_per_step_raw"])
-            if dom and t.get("per_kernel", {}).get(dom):
-                roofline["dominant_kernel_traffic_per_launch"] = t["per_kernel"][dom]["bytes_per_launch_corrected"]
+            if dom and t.get("per_label", {}).get(dom):
+                roofline["dominant_kernel_traffic_per_launch"] = t["per_label"][dom]["bytes_per_launch_corrected"]
         else:
             roofline["traffic_note"] = "%s was measured on another build (source_id %s != %s) or batch: not attached" % (
                 os.path.relpath(tpath, ROOT), t.get("source_id"), source_id())

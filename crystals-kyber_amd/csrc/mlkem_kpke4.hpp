@@ -17,8 +17,12 @@ namespace mlkem {
 #define MLKEM_KPKE4_WAVES 4
 #endif
 constexpr int KPKE4_WAVES = MLKEM_KPKE4_WAVES;
-#ifndef MLKEM_KPKE4_MINWAVES
-#define MLKEM_KPKE4_MINWAVES 4   // waves per SIMD the register allocator aims at (128 VGPRs)
+// waves per SIMD the register allocator aims at: 4 (128 VGPRs) for k = 2, 3; the packed-fp32 form of k = 4 needs 162 VGPRs
+// and would spill 160 B per lane at 128 (measured: 1.87 instead of 1.39 ms per 2^20 items), so it is compiled for 3 waves
+#ifdef MLKEM_KPKE4_MINWAVES
+constexpr int kpke4_minwaves(int) { return MLKEM_KPKE4_MINWAVES; }
+#else
+constexpr int kpke4_minwaves(int k) { return k == 4 ? 3 : 4; }
 #endif
 
 // low 32 bits of {hi, lo} >> s, 0 <= s < 32 (v_alignbit_b32)
@@ -99,7 +103,7 @@ __device__ __forceinline__ void gamma_products(const float (&y)[8], const Tw z10
 // k_decrypt4 — m' = ByteEncode_1(Compress_1(v - InverseNTT(s-hat . NTT(u)))) for four items per wave
 // ------------------------------------------------------------------------------------------------
 template <int K, int DU, int DV>
-__global__ void __launch_bounds__(64 * KPKE4_WAVES, MLKEM_KPKE4_MINWAVES) k_decrypt4(size_t n, const uint8_t* __restrict__ dk, size_t dk_stride,
+__global__ void __launch_bounds__(64 * KPKE4_WAVES, kpke4_minwaves(K)) k_decrypt4(size_t n, const uint8_t* __restrict__ dk, size_t dk_stride,
                                                                 const uint8_t* __restrict__ c, uint8_t* __restrict__ m_out) {
     const int wv = wave_id();
     const RnttLane a = rntt_lane();

@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""tools/gen_results.py <tag> — every measured number DESIGN.md / README.md quote for a round, generated from the committed
+files under profiles/ (so that prose and profiles cannot drift apart):
+
+  profiles/<tag>_bench_default.json      the default `python bench.py` line (headline + also.ntt + also.kem1024)
+  profiles/<tag>_bench_kem512.json, <tag>_bench_shared.json
+  profiles/<tag>_<wl>_kernel_stats.csv   rocprofv3 --kernel-trace --stats of `bench.py --workload <wl> --no-cpu --no-also`
+  profiles/<tag>_pmc_traffic_<wl>.json   FETCH_SIZE / WRITE_SIZE passes (tools/pmc_traffic.py)
+  profiles/<tag>_pmc_sq_<wl>.txt         SQ counters (tools/pmc_summary.py)
+  profiles/<tag>_rehearsal_gpus2.json, <tag>_inproc8.json   the N > 1 forms of the bench line on the one GPU
+  profiles/<tag>_gpu_tier.log            `pytest -m gpu` on the GPU box (test count)
+
+Writes profiles/<tag>_RESULTS.md and replaces the text between `<!-- BEGIN GENERATED <tag> -->` and `<!-- END GENERATED <tag> -->`
+in DESIGN.md and README.md with it."""
+import csv
+import json
+import os
+import re
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r03"
+P = os.path.join(ROOT, "profiles")
+HBM = 8000.0
+ALGO = {"kem768": 5856, "kem1024": 12768, "kem512": 6560, "ntt": 2048}
+
+
+def load(name):
+    path = os.path.join(P, "%s_%s" % (TAG, name))
+    return json.load(open(path)) if os.path.exists(path) else None
+
+
+def short(kernel_name):
+    s = re.sub(r"^void ", "", kernel_name).replace("mlkem::", "")
+    base = s.split("(")[0]
+    m = re.match(r"(k_\w+)<(.*)>$", base)
+    if not m:
+        return base
+    name, targs = m.group(1), m.group(2)
+    if name == "k_encrypt":
+        return "k_encrypt_cmp" if re.search(r",\s*true$", targs) else "k_encrypt"
+    if name == "k_ntt4_batch":
+        return "k_intt_batch" if targs == "true" else "k_ntt_batch"
+    if name == "k_decrypt4":
+        return "k_decrypt"
+    return name
+
+
+def stats(wl):
+    """label -> (calls, avg ms) from the rocprofv3 stats csv; k_sample (list mode) is the bench's k_sample_restart"""
+    path = os.path.join(P, "%s_%s_kernel_stats.csv" % (TAG, wl))
+    out = {}
+    if not os.path.exists(path):
+        return out
+    for r in csv.DictReader(open(path)):
+        n = r["Name"]
+        if "mlkem::" not in n:
+            continue
+        lab = short(n)
+        lab = {"k_sample": "k_sample_restart", "k_sample_resume": "k_sample_tail"}.get(lab, lab)
+        calls, tot = int(r["Calls"]), float(r["TotalDurationNs"])
+        c0, t0 = out.get(lab, (0, 0.0))
+        out[lab] = (c0 + calls, t0 + tot)
+    return {k: (c, t / c / 1e6) for k, (c, t) in out.items()}
+
+
+def fmt(x, d=3):
+    return ("%%.%df" % d) % x
+
+
+def bench_table(j, wl, st):
+    k = j["kernels"]
+    tot = sum(v["ms_total"] for v in k.values())
+    rows = ["| kernel | launches / step | HIP-event avg (ms) | ms / step | share | rocprofv3 avg (ms) over calls |", "|---|---|---|---|---|---|"]
+    for name, v in sorted(k.items(), key=lambda kv: -kv[1]["ms_total"]):
+        rp = st.get(name)
+        rows.append("| `%s` | %d | %s | %s | %.1f %% | %s |" % (name, v["launches"], fmt(v["ms_avg"], 4), fmt(v["ms_total"]), 100 * v["ms_total"] / tot,
+                                                                   ("%s over %d" % (fmt(rp[1], 4), rp[0])) if rp else "—"))
+    return "\n".join(rows)
+
+
+def roofline_lines(j, wl, traffic):
+    rf = j["roofline"]
+    out = ["* roofline (dominant kernel by the algorithmic-bytes rule): **%.1f GB/s = %.3f of the 8 TB/s HBM peak** — %s" % (rf["achieved"], rf["frac"], rf["scope"])]
+    if "whole_pass" in rf:
+        out.append("* whole pass: %.1f GB/s = %.4f of peak (%s)" % (rf["whole_pass"]["achieved"], rf["whole_pass"]["frac"], rf["whole_pass"]["scope"]))
+    if traffic:
+        algo = ALGO[wl] * traffic["batch"]
+        out.append("* HBM traffic by PMC (`profiles/%s_pmc_traffic_%s.json`, git %s, source_id %s): %.2f GB per step corrected (raw %.2f GB) against %.2f GB algorithmic = **%.2f x**" % (
+            TAG, wl, traffic["git_head"], traffic["source_id"], traffic["hbm_bytes_per_step_corrected"] / 1e9, traffic["hbm_bytes_per_step_raw"] / 1e9,
+            algo / 1e9, traffic["hbm_bytes_per_step_corrected"] / algo))
+        dom = rf.get("dominant_kernel")
+        pl = traffic.get("per_label", {}).get(dom)
+        if pl:
+            out.append("  * dominant kernel `%s`: %.3f GB per launch corrected (raw %.3f GB), %d launches per step" % (
+                dom, pl["bytes_per_launch_corrected"] / 1e9, pl["bytes_per_launch_raw"] / 1e9, pl["launches_per_step"]))
+    cp = rf.get("clock_power")
+    if cp:
+        out.append("* clock / power behind the timed region: shader clock median %s MHz (nominal %s), socket power median %s W (cap %s W)" % (
+            cp["sclk_mhz"]["median"], cp["sclk_nominal_mhz"], cp["socket_w"]["median"], cp["power_cap_w"]))
+    return "\n".join(out)
+
+
+def cpu_lines(cb):
+    if not cb:
+        return ""
+    out = []
+    legs = cb.get("legs") or {"(single leg)": cb}
+    for name, v in legs.items():
+        out.append("  * `%s`: %s %s on %d cores (%.2f per core), outputs match GPU: %s — %s" % (
+            name, ("%.4g" % v["value"]), v["unit"], v["cores"], v.get("per_core", float("nan")), v["outputs_match_gpu"], v["sample"]))
+    return "\n".join(out)
+
+
+def sq_lines(wl):
+    path = os.path.join(P, "%s_pmc_sq_%s.txt" % (TAG, wl))
+    if not os.path.exists(path):
+        return ""
+    rows = ["| kernel | cycles per VALU instruction | resident waves / SIMD |", "|---|---|---|"]
+    for ln in open(path):
+        m = re.search(r"^(\S+) dispatches=.*cycles_per_valu_instr=([\d.]+) resident_waves_per_simd=([\d.]+)", ln)
+        if m:
+            rows.append("| `%s` | %s | %s |" % (m.group(1), m.group(2), m.group(3)))
+    return "\n".join(rows) if len(rows) > 2 else ""
+
+
+def main():
+    d = load("bench_default.json")
+    if d is None:
+        raise SystemExit("profiles/%s_bench_default.json missing" % TAG)
+    L = []
+    L.append("_Generated by `tools/gen_results.py %s` from the files under `profiles/%s_*`; do not edit by hand._\n" % (TAG, TAG))
+    L.append("**Headline (BASELINE configs[2])**: `python bench.py` → **%.3g %s**, %.2f ms per step of 2^20 pairs, `correct: %s` (`profiles/%s_bench_default.json`).\n" % (
+        d["value"], d["unit"], d["ms_per_step"], d["correct"], TAG))
+    st = stats("kem768")
+    L.append(bench_table(d, "kem768", st))
+    L.append("")
+    L.append(roofline_lines(d, "kem768", load("pmc_traffic_kem768.json")))
+    L.append("* CPU baseline legs (same items, bytes compared with the GPU's):\n" + cpu_lines(d.get("cpu_baseline")))
+    L.append("")
+    for wl, title in (("ntt", "configs[1]: NTT fwd+inv"), ("kem1024", "configs[3]: ML-KEM-1024 keygen+encaps+decaps")):
+        e = d.get("also", {}).get(wl)
+        if not e:
+            continue
+        L.append("**%s** (same process, `also.%s`): **%.3g %s**, %.3f ms per step, `correct: %s`\n" % (title, wl, e["value"], e["unit"], e["ms_per_step"], e["correct"]))
+        L.append(bench_table(e, wl, stats(wl)))
+        L.append("")
+        L.append(roofline_lines(e, wl, load("pmc_traffic_%s.json" % wl)))
+        if e.get("cpu_baseline"):
+            L.append("* CPU baseline:\n" + cpu_lines(e["cpu_baseline"]))
+        L.append("")
+    for name, title in (("bench_kem512.json", "ML-KEM-512 keygen+encaps+decaps"), ("bench_shared.json", "ML-KEM-768, one key pair for the whole batch (extra workload)")):
+        j = load(name)
+        if j:
+            L.append("**%s**: %.3g %s, %.2f ms per step, `correct: %s` (`profiles/%s_%s`)\n" % (title, j["value"], j["unit"], j["ms_per_step"], j["correct"], TAG, name))
+    sq = sq_lines("kem768")
+    if sq:
+        L.append("**Issue utilisation, ML-KEM-768** (`profiles/%s_pmc_sq_kem768.txt`; 2.0 cycles = a full-rate wave64 instruction on a SIMD-32):\n" % TAG)
+        L.append(sq)
+        L.append("")
+    for name, title in (("rehearsal_gpus2.json", "`bench.py --gpus 2 --rehearse` under torch.distributed.run (two ranks share the one GPU, gloo barrier)"),
+                        ("inproc8.json", "`bench.py --inproc --gpus 8` (one process, eight members through `mlkem_*_multi_dev`, all on the one GPU)")):
+        j = load(name)
+        if not j:
+            continue
+        L.append("**N > 1 line on the one GPU — %s**: aggregate %.3g %s, %.2f ms per step, `correct: %s`; `per_gpu`:\n" % (title, j["value"], j["unit"], j["ms_per_step"], j["correct"]))
+        L.append("| rank | device | %s | ms / step | sclk MHz | socket W | correct |" % j["unit"])
+        L.append("|---|---|---|---|---|---|---|")
+        for p in j["per_gpu"]:
+            L.append("| %d | %d | %.3g | %.2f | %s | %s | %s |" % (p["rank"], p["device"], p["value"], p["ms_per_step"], p["sclk_mhz"], p["socket_w"], p["correct"]))
+        L.append("")
+    log = os.path.join(P, "%s_gpu_tier.log" % TAG)
+    if os.path.exists(log):
+        m = re.search(r"(\d+) passed", open(log).read())
+        if m:
+            L.append("**GPU tier**: %s tests passed on MI355X (`profiles/%s_gpu_tier.log`).\n" % (m.group(1), TAG))
+    text = "\n".join(L).rstrip() + "\n"
+    open(os.path.join(P, "%s_RESULTS.md" % TAG), "w").write(text)
+    for doc in ("DESIGN.md", "README.md"):
+        path = os.path.join(ROOT, doc)
+        s = open(path).read()
+        b, e = "<!-- BEGIN GENERATED %s -->" % TAG, "<!-- END GENERATED %s -->" % TAG
+        if b in s and e in s:
+            s = s[:s.index(b) + len(b)] + "\n" + text + s[s.index(e):]
+            open(path, "w").write(s)
+            print("updated", doc)
+        else:
+            print("no marker for", TAG, "in", doc)
+    print("wrote profiles/%s_RESULTS.md (%d lines)" % (TAG, text.count("\n")))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,10 +1,13 @@
 #!/bin/bash
-# tools/profile_round.sh <tag> — the rocprofv3 passes a round's profiles/ are made from, run on the GPU box:
-#   kernel-trace + stats of bench.py for kem768 / ntt / kem1024, and two PMC passes each (FETCH_SIZE, WRITE_SIZE; separate
-#   runs, as MI355X_MICROARCH.md prescribes) whose CSVs tools/pmc_traffic.py turns into profiles/rNN_pmc_traffic_*.json.
+# tools/profile_round.sh <tag> — the rocprofv3 passes a round's profiles/ are made from, run on the GPU box at a COMMITTED
+# HEAD (the stamps in the summaries name that commit):
+#   per workload (kem768 / ntt / kem1024): kernel-trace + stats of bench.py, two PMC passes (FETCH_SIZE, WRITE_SIZE; separate
+#   runs, as MI355X_MICROARCH.md prescribes) whose CSVs tools/pmc_traffic.py turns into profiles/rNN_pmc_traffic_*.json, and
+#   an SQ pass (issue utilisation);
+#   the default bench line, the two-rank rehearsal (torch.distributed.run, per_gpu) and the in-process 8-member line.
 # Output: gpurun_out/prof_<tag>/.   The program after `--` is python3 itself (no env / bash -c hop under the profiler).
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
@@ -16,13 +19,22 @@ run() {   # name, rocprof args..., -- bench args
     grep -h '^{' "$OUT/$name.log" | tail -1 > "$OUT/$name.bench.json"
 }
 for wl in kem768 ntt kem1024; do
-    steps=10; [ $wl = ntt ] && steps=100
-    run kt_$wl --kernel-trace --stats --output-format csv -d "$OUT/kt_$wl" -o $wl -- python3 "$ROOT/bench.py" --workload $wl --no-cpu --no-also --steps $steps --warmup 2 || exit 1
+    run kt_$wl --kernel-trace --stats --output-format csv -d "$OUT/kt_$wl" -o $wl -- python3 "$ROOT/bench.py" --workload $wl --no-cpu --no-also || exit 1
     run fetch_$wl --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/fetch_$wl" -o $wl -- python3 "$ROOT/bench.py" --workload $wl --no-cpu --no-also --steps 3 --warmup 1 || exit 1
     run write_$wl --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/write_$wl" -o $wl -- python3 "$ROOT/bench.py" --workload $wl --no-cpu --no-also --steps 3 --warmup 1 || exit 1
     # SQ view of the same command: issue utilisation (VALU instructions per SIMD-cycle), waiting, LDS use
     run sq_$wl --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_LDS SQ_INSTS_SALU GRBM_GUI_ACTIVE \
         --kernel-trace --output-format csv -d "$OUT/sq_$wl" -o $wl -- python3 "$ROOT/bench.py" --workload $wl --no-cpu --no-also --steps 3 --warmup 1 || exit 1
 done
+cd "$ROOT"
+echo "== bench lines" >&2
+timeout -k 10 400 python3 bench.py > "$OUT/bench_default.json" 2> "$OUT/bench_default.err" || { echo "FAILED default bench" >&2; exit 1; }
+for wl in kem512 kem768_shared; do
+    timeout -k 10 300 python3 bench.py --workload $wl > "$OUT/bench_$wl.json" 2> "$OUT/bench_$wl.err" || { echo "FAILED $wl" >&2; exit 1; }
+done
+timeout -k 10 400 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --rehearse \
+    > "$OUT/rehearsal_gpus2.log" 2> "$OUT/rehearsal_gpus2.err" || { echo "FAILED rehearsal" >&2; exit 1; }
+grep -h '^{' "$OUT/rehearsal_gpus2.log" | tail -1 > "$OUT/rehearsal_gpus2.json"
+timeout -k 10 400 python3 bench.py --inproc --gpus 8 > "$OUT/inproc8.json" 2> "$OUT/inproc8.err" || { echo "FAILED inproc" >&2; exit 1; }
 find "$OUT" -name '*.csv' | sed "s|$ROOT/||" | sort
 du -sh "$OUT"

@@ -1,17 +1,30 @@
 #!/bin/bash
-# Turn the raw output of tools/profile_round.sh <tag> (gpurun_out/prof_<tag>/) into the committed round-2 summaries:
-#   profiles/r02_<wl>_kernel_stats.csv, profiles/r02_pmc_traffic_<wl>.json (tied to the kernel sources by source_id),
-#   profiles/r02_pmc_sq_<wl>.txt.     Usage: tools/refresh_profiles.sh <tag>
+# Turn the raw output of tools/profile_round.sh <tag> (gpurun_out/prof_<tag>/) into the committed summaries of the round
+#   profiles/<tag>_<wl>_kernel_stats.csv, profiles/<tag>_pmc_traffic_<wl>.json (tied to the kernel sources by source_id and
+#   stamped with the commit), profiles/<tag>_pmc_sq_<wl>.txt, profiles/<tag>_bench_*.json, profiles/<tag>_rehearsal_gpus2.json,
+#   profiles/<tag>_inproc8.json -- and regenerate the tables of DESIGN.md / README.md from them (tools/gen_results.py).
+# Refuses to run on a dirty kernel tree: a profile of uncommitted sources cannot be reproduced from a commit.
+# Usage: tools/refresh_profiles.sh <tag>
 T=${1:?tag}; D=gpurun_out/prof_$T
+if [ -n "$(git status --porcelain -- crystals-kyber_amd/csrc include bench.py)" ]; then
+  echo "kernel sources / bench.py differ from HEAD: commit first, then profile and refresh" >&2; exit 1
+fi
 for wl in kem768 ntt kem1024; do
-  cp $D/kt_$wl/${wl}_kernel_stats.csv profiles/r02_${wl}_kernel_stats.csv || exit 1
+  cp $D/kt_$wl/${wl}_kernel_stats.csv profiles/${T}_${wl}_kernel_stats.csv || exit 1
   python tools/pmc_traffic.py --fetch $D/fetch_$wl/${wl}_counter_collection.csv --write $D/write_$wl/${wl}_counter_collection.csv \
-      --bench $D/fetch_$wl.bench.json --workload $wl --out profiles/r02_pmc_traffic_$wl.json | tail -1 || exit 1
-  python tools/pmc_summary.py $D/sq_$wl/${wl}_counter_collection.csv --filter k_ > profiles/r02_pmc_sq_$wl.txt || exit 1
+      --bench $D/fetch_$wl.bench.json --workload $wl --out profiles/${T}_pmc_traffic_$wl.json | tail -1 || exit 1
+  python tools/pmc_summary.py $D/sq_$wl/${wl}_counter_collection.csv --filter k_ > profiles/${T}_pmc_sq_$wl.txt || exit 1
 done
-python - <<'P'
-import json, bench
+cp $D/bench_default.json profiles/${T}_bench_default.json
+cp $D/bench_kem512.json profiles/${T}_bench_kem512.json
+cp $D/bench_kem768_shared.json profiles/${T}_bench_shared.json
+cp $D/rehearsal_gpus2.json profiles/${T}_rehearsal_gpus2.json
+cp $D/inproc8.json profiles/${T}_inproc8.json
+python - $T <<'P'
+import json, sys, bench
+t = sys.argv[1]
 for w in ("kem768", "ntt", "kem1024"):
-    d = json.load(open("profiles/r02_pmc_traffic_%s.json" % w))
-    print(w, "source_id", d["source_id"], "matches build:", d["source_id"] == bench.source_id())
+    d = json.load(open("profiles/%s_pmc_traffic_%s.json" % (t, w)))
+    print(w, "source_id", d["source_id"], "git", d["git_head"], "matches build:", d["source_id"] == bench.source_id())
 P
+python tools/gen_results.py $T
