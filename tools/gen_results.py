@@ -118,7 +118,7 @@ def sq_lines(wl):
         return ""
     rows = ["| kernel | cycles per VALU instruction | resident waves / SIMD |", "|---|---|---|"]
     for ln in open(path):
-        m = re.search(r"^(\S+) dispatches=.*cycles_per_valu_instr=([\d.]+) resident_waves_per_simd=([\d.]+)", ln)
+        m = re.search(r"^(.+?) dispatches=.*cycles_per_valu_instr=([\d.]+) resident_waves_per_simd=([\d.]+)", ln)
         if m:
             rows.append("| `%s` | %s | %s |" % (m.group(1), m.group(2), m.group(3)))
     return "\n".join(rows) if len(rows) > 2 else ""
