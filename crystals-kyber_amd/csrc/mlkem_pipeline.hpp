@@ -16,6 +16,7 @@
 #include "mlkem_arith.hpp"
 #include "mlkem_rntt.hpp"
 #include "mlkem_kpke4.hpp"
+#include "mlkem_kpke2.hpp"
 #include <stdlib.h>
 #ifndef MLKEM_EMU
 #include <vector>
@@ -160,6 +161,19 @@ inline void launch_sample(stream_t st, const ParamSet& p, size_t n, const uint8_
     launch_sample_split(st, p, n, n, rho, rho_stride, transpose, r, prf_per_item, n_eta1, ws);
 }
 
+// K-PKE.Encrypt launch: two items per wave with packed fp32 (mlkem_kpke2.hpp) where its output pieces exist (du = 10, dv = 4:
+// k = 2, 3), one item per wave (mlkem_arith.hpp) otherwise
+#ifndef MLKEM_KPKE2
+#define MLKEM_KPKE2 1
+#endif
+template <int K, int ETA1, int DU, int DV, bool CMP, class... Args>
+inline void encrypt_launch(const char* label, stream_t st, size_t n, Args... args) {
+    if constexpr (MLKEM_KPKE2 && DU == 10 && DV == 4)
+        launch(label, k_encrypt2<K, ETA1, DU, DV, CMP>, ceil_div(ceil_div(n, 2), KPKE2_WAVES), WAVE * KPKE2_WAVES, st, n, args...);
+    else
+        launch(label, k_encrypt<K, ETA1, DU, DV, CMP>, ceil_div(n, ARITH_WAVES), WAVE * ARITH_WAVES, st, n, args...);
+}
+
 // ---- ML-KEM.KeyGen_internal (ml_kem.c:1034-1084) ; z == nullptr: K-PKE.KeyGen alone (ml_kem.c:651-769, dk = 384k-byte ŝ) ----
 template <int K, int ETA1>
 inline void keygen_run(stream_t st, const ParamSet& p, size_t n, const uint8_t* d, const uint8_t* z, uint8_t* ek, uint8_t* dk,
@@ -201,8 +215,7 @@ inline void encaps_run(stream_t st, const ParamSet& p, size_t n, const uint8_t* 
             const size_t cn = min_sz(ws.cap, hn - c0), i0 = h0 + c0;
             const uint8_t* eki = ek + i0 * p.ek_len;
             launch_sample(st, p, cn, eki + 384 * K, p.ek_len, /*transpose=*/1, r_h + c0 * 32, 2 * K + 1, K, ws);
-            launch("k_encrypt", k_encrypt<K, ETA1, DU, DV, false>, ceil_div(cn, ARITH_WAVES), WAVE * ARITH_WAVES,
-                   st, cn, eki, (size_t)p.ek_len, m + i0 * 32, (const uint16_t*)ws.A, (const uint8_t*)ws.prf,
+            encrypt_launch<K, ETA1, DU, DV, false>("k_encrypt", st, cn, eki, (size_t)p.ek_len, m + i0 * 32, (const uint16_t*)ws.A, (const uint8_t*)ws.prf,
                    c + i0 * p.c_len, (const uint8_t*)nullptr, (const uint8_t*)nullptr, (const uint8_t*)nullptr, (uint8_t*)nullptr,
                    mod_status ? mod_status + i0 : (int32_t*)nullptr, (size_t)(K * K * 256));
         }
@@ -241,8 +254,7 @@ inline void decaps_run(stream_t st, const ParamSet& p, size_t n, const uint8_t* 
             const size_t cn = min_sz(ws.cap, hn - c0), i0 = h0 + c0;
             const uint8_t* dki = dk + i0 * p.dk_len;
             launch_sample(st, p, cn, dki + 768 * K, p.dk_len, /*transpose=*/1, ws.r + c0 * 32, 2 * K + 1, K, ws);
-            launch("k_encrypt_cmp", k_encrypt<K, ETA1, DU, DV, true>, ceil_div(cn, ARITH_WAVES), WAVE * ARITH_WAVES,
-                   st, cn, dki + 384 * K, (size_t)p.dk_len, (const uint8_t*)(ws.m + c0 * 32), (const uint16_t*)ws.A,
+            encrypt_launch<K, ETA1, DU, DV, true>("k_encrypt_cmp", st, cn, dki + 384 * K, (size_t)p.dk_len, (const uint8_t*)(ws.m + c0 * 32), (const uint16_t*)ws.A,
                    (const uint8_t*)ws.prf, (uint8_t*)nullptr, c + i0 * p.c_len, (const uint8_t*)(ws.Kp + c0 * 32),
                    (const uint8_t*)(ws.Kbar + c0 * 32), Kout + i0 * 32, (int32_t*)nullptr, (size_t)(K * K * 256));
         }
@@ -265,7 +277,7 @@ inline void encaps_shared_run(stream_t st, const ParamSet& p, size_t n, const ui
         for (size_t c0 = 0; c0 < hn; c0 += ws.cap) {
             const size_t cn = min_sz(ws.cap, hn - c0), i0 = h0 + c0;
             launch_sample_split(st, p, 0, cn, nullptr, 0, 1, ws.r + c0 * 32, 2 * K + 1, K, w);      // PRF rows per item
-            launch("k_encrypt", k_encrypt<K, ETA1, DU, DV, false>, ceil_div(cn, ARITH_WAVES), WAVE * ARITH_WAVES, st, cn, ek, (size_t)0,
+            encrypt_launch<K, ETA1, DU, DV, false>("k_encrypt", st, cn, ek, (size_t)0,
                    m + i0 * 32, (const uint16_t*)w.A, (const uint8_t*)w.prf, c + i0 * p.c_len, (const uint8_t*)nullptr,
                    (const uint8_t*)nullptr, (const uint8_t*)nullptr, (uint8_t*)nullptr, (int32_t*)nullptr, (size_t)0);
         }
@@ -293,7 +305,7 @@ inline void decaps_shared_run(stream_t st, const ParamSet& p, size_t n, const ui
         for (size_t c0 = 0; c0 < hn; c0 += ws.cap) {
             const size_t cn = min_sz(ws.cap, hn - c0), i0 = h0 + c0;
             launch_sample_split(st, p, 0, cn, nullptr, 0, 1, ws.r + c0 * 32, 2 * K + 1, K, w);
-            launch("k_encrypt_cmp", k_encrypt<K, ETA1, DU, DV, true>, ceil_div(cn, ARITH_WAVES), WAVE * ARITH_WAVES, st, cn, dk + 384 * K,
+            encrypt_launch<K, ETA1, DU, DV, true>("k_encrypt_cmp", st, cn, dk + 384 * K,
                    (size_t)0, (const uint8_t*)(ws.m + c0 * 32), (const uint16_t*)w.A, (const uint8_t*)w.prf, (uint8_t*)nullptr, c + i0 * p.c_len,
                    (const uint8_t*)(ws.Kp + c0 * 32), (const uint8_t*)(ws.Kbar + c0 * 32), Kout + i0 * 32, (int32_t*)nullptr, (size_t)0);
         }
