@@ -45,7 +45,7 @@ constexpr int KPKE2_WAVES = MLKEM_KPKE2_WAVES;
 #ifdef MLKEM_KPKE2_MINWAVES
 constexpr int kpke2_minwaves(int) { return MLKEM_KPKE2_MINWAVES; }
 #else
-constexpr int kpke2_minwaves(int k) { return k == 2 ? 4 : 3; }   // k = 3: 140-157 VGPRs; two, three waves measured equal, four spill
+constexpr int kpke2_minwaves(int k) { return k == 2 ? 4 : k == 3 ? 3 : 2; }   // k = 3: 140-157 VGPRs; two, three waves measured equal, four spill
 #endif
 
 // exchange buffers of one wave: NP polynomials in flight per item (their transforms are interleaved instruction by
@@ -338,7 +338,7 @@ __device__ __forceinline__ void k2_compress4(const v2f (&x)[4], unsigned (&c)[8]
     }
 }
 
-// value of lane `lane ^ 1` (the other lane of an even / odd pair)
+// value of lane `lane ^ 1` (the other lane of an even / odd pair) / of the previous lane of the quad (lane 0 of a quad: itself)
 __device__ __forceinline__ uint32_t k2_swap1(uint32_t v) {
 #ifdef MLKEM_EMU
     return (uint32_t)__shfl((int)v, (int)((threadIdx.x & 63) ^ 1));
@@ -346,17 +346,47 @@ __device__ __forceinline__ uint32_t k2_swap1(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true);   // quad_perm:[1,0,3,2]
 #endif
 }
+__device__ __forceinline__ uint32_t k2_prev_in_quad(uint32_t v) {
+#ifdef MLKEM_EMU
+    const int l = (int)(threadIdx.x & 63);
+    return (uint32_t)__shfl((int)v, (l & 3) ? l - 1 : l);
+#else
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x90, 0xF, 0xF, true);   // quad_perm:[0,0,1,2]
+#endif
+}
+// (hi:lo) << s, bits 32..63, for s in {0, 8, 16, 24} (lane-dependent)
+__device__ __forceinline__ uint32_t k2_shl_hi(uint32_t hi, uint32_t lo, unsigned s) {
+    return s ? __builtin_amdgcn_alignbit(hi, lo, 32u - s) : hi;
+}
 
 // ByteEncode_D of the lane's 8 D-bit values (ml_kem.c:125-145): the lane owns bytes [D t, D t + D) of the polynomial's 32 D
-// bytes.  `Words` = the dwords this lane stores / compares and where (dword index inside the polynomial).
+// bytes.  A piece = the dwords this lane stores / compares.  Where neighbouring lanes share a dword, ONE of them owns it and
+// receives the other's bits by a DPP move:
+//   D = 4, 12 : 1 / 3 dwords per lane, dword aligned
+//   D = 10    : 80 bits; two lanes cover 5 dwords: the even lane stores dwords 0, 1 and the shared dword 2, the odd lane 3, 4
+//   D = 11    : 88 bits; four lanes cover 11 dwords; lane j of the quad starts at bit 88 j = dword {0, 2, 5, 8} + {0, 24, 16, 8}
+//               bits; a lane owns the dword it STARTS in (lanes 1-3 merge the previous lane's last bits): 2, 3, 3, 3 dwords
+//   D = 5     : 40 bits; four lanes cover 5 dwords; lane j starts at dword j + 8 j bits; lanes own 1, 1, 1, 2 dwords
 template <int D>
 struct K2Piece {
-    static_assert(D == 4 || D == 10 || D == 12, "piece shapes built so far: dv = 4, du = 10, ByteEncode_12 (k = 2, 3)");
-    static constexpr int NW = D == 4 ? 1 : 3;
+    static_assert(D == 4 || D == 5 || D == 10 || D == 11 || D == 12, "ciphertext / key encodings of ML-KEM");
+    static constexpr int NW = D == 4 ? 1 : D == 5 ? 2 : 3;
     uint32_t w[NW];
-    // dword index of w[0] inside the polynomial, and how many of the lane's dwords are valid (D = 10: 3 in even lanes, 2 in odd)
-    static __device__ __forceinline__ int first(int t) { return D == 4 ? t : D == 12 ? 3 * t : 5 * (t >> 1) + ((t & 1) ? 3 : 0); }
-    static __device__ __forceinline__ int count(int t) { return D == 4 ? 1 : D == 12 ? 3 : ((t & 1) ? 2 : 3); }
+    // dword index of w[0] inside the polynomial, and how many of the lane's dwords are valid
+    static __device__ __forceinline__ int first(int t) {
+        if constexpr (D == 4) return t;
+        else if constexpr (D == 12) return 3 * t;
+        else if constexpr (D == 10) return 5 * (t >> 1) + ((t & 1) ? 3 : 0);
+        else if constexpr (D == 11) return 11 * (t >> 2) + ((88 * (t & 3)) >> 5);
+        else return 5 * (t >> 2) + (t & 3);
+    }
+    static __device__ __forceinline__ int count(int t) {
+        if constexpr (D == 4) return 1;
+        else if constexpr (D == 12) return 3;
+        else if constexpr (D == 10) return (t & 1) ? 2 : 3;
+        else if constexpr (D == 11) return (t & 3) ? 3 : 2;
+        else return (t & 3) == 3 ? 2 : 1;
+    }
 };
 template <int D>
 __device__ __forceinline__ void k2_encode(const unsigned (&c)[8], int t, K2Piece<D>& o) {
@@ -366,18 +396,39 @@ __device__ __forceinline__ void k2_encode(const unsigned (&c)[8], int t, K2Piece
         o.w[0] = c[0] | (c[1] << 12) | (c[2] << 24);
         o.w[1] = (c[2] >> 8) | (c[3] << 4) | (c[4] << 16) | (c[5] << 28);
         o.w[2] = (c[5] >> 4) | (c[6] << 8) | (c[7] << 20);
-    } else {
-        // 80 bits: v0 = bits 0..31, v1 = bits 32..63, v2 = bits 64..79.  Two lanes (t even, t odd) cover 5 dwords; the even
-        // lane stores dwords 0, 1 and the shared dword 2 (its v2 | the odd lane's low 16 bits), the odd lane dwords 3, 4.
+    } else if constexpr (D == 10) {
+        // 80 bits: v0 = bits 0..31, v1 = bits 32..63, v2 = bits 64..79
         const uint32_t v0 = c[0] | (c[1] << 10) | (c[2] << 20) | (c[3] << 30);
         const uint32_t v1 = (c[3] >> 2) | (c[4] << 8) | (c[5] << 18) | (c[6] << 28);
         const uint32_t v2 = (c[6] >> 4) | (c[7] << 6);
         const uint32_t other0 = k2_swap1(v0);
-        const bool odd = (t & 1) != 0;
-        const unsigned sh = odd ? 16u : 0u;
+        const unsigned sh = (t & 1) ? 16u : 0u;
         o.w[0] = __builtin_amdgcn_alignbit(v1, v0, sh);             // even: v0          odd: bits 16..47
         o.w[1] = __builtin_amdgcn_alignbit(v2, v1, sh);             // even: v1          odd: bits 48..79
         o.w[2] = v2 | (other0 << 16);                               // even: shared dword (odd lanes do not use it)
+    } else if constexpr (D == 11) {
+        // 88 bits: v0, v1, v2 (24 bits), shifted to the lane's bit offset s inside its first dword
+        const uint32_t v0 = c[0] | (c[1] << 11) | (c[2] << 22);
+        const uint32_t v1 = (c[2] >> 10) | (c[3] << 1) | (c[4] << 12) | (c[5] << 23);
+        const uint32_t v2 = (c[5] >> 9) | (c[6] << 2) | (c[7] << 13);
+        const int j = t & 3;
+        const unsigned sh = (88u * (unsigned)j) & 31u;              // 0, 24, 16, 8
+        const uint32_t e0 = v0 << sh, e1 = k2_shl_hi(v1, v0, sh), e2 = k2_shl_hi(v2, v1, sh), e3 = k2_shl_hi(0u, v2, sh);
+        const uint32_t tail = j == 0 ? e2 : e3;                     // the bits in the dword the NEXT lane owns
+        const uint32_t prev = k2_prev_in_quad(tail);
+        o.w[0] = e0 | (j ? prev : 0u);
+        o.w[1] = e1;
+        o.w[2] = e2;                                                // lane 0 of the quad: not stored (count = 2)
+    } else {
+        // 40 bits: v0, v1 (8 bits)
+        const uint32_t v0 = c[0] | (c[1] << 5) | (c[2] << 10) | (c[3] << 15) | (c[4] << 20) | (c[5] << 25) | (c[6] << 30);
+        const uint32_t v1 = (c[6] >> 2) | (c[7] << 3);
+        const int j = t & 3;
+        const unsigned sh = 8u * (unsigned)j;
+        const uint32_t e0 = v0 << sh, e1 = k2_shl_hi(v1, v0, sh);
+        const uint32_t prev = k2_prev_in_quad(e1);
+        o.w[0] = e0 | (j ? prev : 0u);
+        o.w[1] = e1;                                                // lane 3 of the quad only (count = 2)
     }
 }
 template <int D>

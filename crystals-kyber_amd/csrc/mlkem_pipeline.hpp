@@ -161,14 +161,14 @@ inline void launch_sample(stream_t st, const ParamSet& p, size_t n, const uint8_
     launch_sample_split(st, p, n, n, rho, rho_stride, transpose, r, prf_per_item, n_eta1, ws);
 }
 
-// K-PKE.Encrypt launch: two items per wave with packed fp32 (mlkem_kpke2.hpp) where its output pieces exist (du = 10, dv = 4:
-// k = 2, 3), one item per wave (mlkem_arith.hpp) otherwise
+// K-PKE.Encrypt launch: two items per wave with packed fp32 (mlkem_kpke2.hpp); MLKEM_KPKE2=0 builds the one-item-per-wave LDS
+// form of mlkem_arith.hpp instead (A/B)
 #ifndef MLKEM_KPKE2
 #define MLKEM_KPKE2 1
 #endif
 template <int K, int ETA1, int DU, int DV, bool CMP, class... Args>
 inline void encrypt_launch(const char* label, stream_t st, size_t n, Args... args) {
-    if constexpr (MLKEM_KPKE2 && DU == 10 && DV == 4)
+    if constexpr (MLKEM_KPKE2 != 0)
         launch(label, k_encrypt2<K, ETA1, DU, DV, CMP>, ceil_div(ceil_div(n, 2), KPKE2_WAVES), WAVE * KPKE2_WAVES, st, n, args...);
     else
         launch(label, k_encrypt<K, ETA1, DU, DV, CMP>, ceil_div(n, ARITH_WAVES), WAVE * ARITH_WAVES, st, n, args...);
