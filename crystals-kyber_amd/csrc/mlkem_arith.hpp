@@ -1,15 +1,11 @@
-// mlkem_arith.hpp — wave-per-instance polynomial kernels: K-PKE KeyGen / Encrypt / Decrypt (ml_kem.c:651-1023) after
-// hashing and sampling, plus the stand-alone NTT / MultiplyNTTs / CBD primitives.
+// mlkem_arith.hpp — stand-alone polynomial primitives of the C-ABI (MultiplyNTTs, VectorMultiply, PolyAddition /
+// PolySubtraction, SamplePolyCBD, Compress / Decompress, ByteEncode / ByteDecode, cell converters) and the CBD evaluation
+// shared with the K-PKE kernels.  The K-PKE kernels themselves live in mlkem_kpke2.hpp (KeyGen, Encrypt: two items per wave,
+// packed fp32) and mlkem_kpke4.hpp (Decrypt: four items per wave); the stand-alone transforms in mlkem_rntt.hpp.
 //
-// One wavefront owns one KEM instance (or one polynomial); each lane holds 4 coefficients (NAT layout: 4l..4l+3,
-// which is also the base-case-multiply pair layout and the HBM layout).  Modular arithmetic runs exactly on the
-// fp32 pipe (mlkem_fntt.hpp); Compress / ByteEncode / ByteDecode are integer work on a wave-private LDS byte buffer.
-// No workgroup barrier is used: the 4 waves of a workgroup are independent.
-//
-// Memory-latency structure (profiles/r01_pmc_sq_arith_before_prefetch.txt: 57 % of a wave's life was s_waitcnt): the wave-LDS fences are
-// compiler barriers, so a load written next to its use is issued next to its use.  Every kernel therefore issues ALL
-// of its prologue loads (PRF bytes, packed key / ciphertext polynomials, message bits) before the first NTT, and the
-// rows of the sampled matrix are double-buffered: row a+1 is requested before row a is consumed.
+// Here one wavefront owns one polynomial, each lane holds 4 coefficients (NAT layout: 4l..4l+3, which is also the base-case
+// multiply pair layout and the HBM layout).  Modular arithmetic runs exactly on the fp32 pipe (mlkem_fntt.hpp); the byte
+// codecs work on a wave-private LDS byte buffer.  No workgroup barrier is used: the 4 waves of a workgroup are independent.
 #pragma once
 #include "mlkem_fntt.hpp"
 
@@ -19,48 +15,13 @@ namespace mlkem {
 #define MLKEM_ARITH_WAVES 4
 #endif
 constexpr int ARITH_WAVES = MLKEM_ARITH_WAVES;   // waves per workgroup (each fully independent)
-// __launch_bounds__ second argument of the K-PKE kernels = resident waves per SIMD the register allocator aims at.  The
-// kernels hide their LDS-exchange latency with occupancy (A/B on one box: 6 waves beat 5 by 3-4 % in k_encrypt<3>, 7 beat 6
-// by another 2-3 %, profiles/r03_kpke_experiments.txt; a loop-over-items form with 13 % fewer instructions but 4 waves was
-// slower): 7 where the LDS block allows it (k = 2, 3: 16-22 KB per workgroup; the build uses -fno-slp-vectorize, under which
-// k_encrypt<3> needs 66-69 VGPRs), 5 for k = 4 (28 KB).  MLKEM_ARITH_MINWAVES overrides for experiments.
-#ifdef MLKEM_ARITH_MINWAVES
-constexpr int arith_minwaves(int) { return MLKEM_ARITH_MINWAVES; }
-#else
-constexpr int arith_minwaves(int k) { return k == 4 ? 5 : 7; }
-#endif
-
-template <int K>
-struct __attribute__((aligned(16))) ArithLds {
-    float xch[256];         // NTT exchange buffer; between transforms it doubles as the codec byte buffer (cbuf())
-    float vhat[K][256];     // NTT-domain vector (y-hat or s-hat), reduced
-    float vgam[K][128];     // its odd coefficients times gamma (ml_kem.c:402-403)
-    // The codec byte buffer lives in the exchange buffer: a codec step never overlaps a transform of the same wave, both sides
-    // fence their LDS traffic, and a wave's DS operations execute in issue order.  5.5 instead of 5.9 KB per wave at k = 3, so
-    // that a seventh workgroup fits the CU's 160 KB.
-    __device__ __forceinline__ uint32_t* cbuf() { return reinterpret_cast<uint32_t*>(xch); }
-};
-static_assert(CODEC_BUF_WORDS * 4 <= 256 * 4, "the codec buffer must fit the exchange buffer");
-
 __device__ __forceinline__ void store_poly_nat(uint16_t* p, const int (&x)[4]) {
     uint2 v;
     v.x = ((uint32_t)x[0] & 0xFFFFu) | ((uint32_t)x[1] << 16);
     v.y = ((uint32_t)x[2] & 0xFFFFu) | ((uint32_t)x[3] << 16);
     *reinterpret_cast<uint2*>(p + 4 * lane_id()) = v;
 }
-__device__ __forceinline__ uint2 load_poly_raw(const uint16_t* p) { return stream_load8(p + 4 * lane_id()); }
-__device__ __forceinline__ void poly_raw_to_f(const uint2 v, float (&x)[4]) {
-    x[0] = (float)(v.x & 0xFFFFu); x[1] = (float)(v.x >> 16);
-    x[2] = (float)(v.y & 0xFFFFu); x[3] = (float)(v.y >> 16);
-}
-
-// ---- SamplePolyCBD (ml_kem.c:253-275), split into the load of the lane's 8*ETA bits and their evaluation --------
-template <int ETA>
-__device__ __forceinline__ uint32_t cbd_load(const uint8_t* prf) {
-    const int l = lane_id();
-    if constexpr (ETA == 2) return *reinterpret_cast<const uint16_t*>(prf + 2 * l);   // 4 coefficients = 16 bits
-    else return (uint32_t)prf[3 * l] | ((uint32_t)prf[3 * l + 1] << 8) | ((uint32_t)prf[3 * l + 2] << 16);   // 24 bits
-}
+// ---- SamplePolyCBD (ml_kem.c:253-275): evaluation of 4 coefficients from their 8*ETA bits ------------------------------
 template <int ETA>
 __device__ __forceinline__ void cbd_eval_f(uint32_t t, float (&x)[4]) {
     if constexpr (ETA == 2) {
@@ -153,206 +114,6 @@ __device__ __forceinline__ void emit_encode12(uint32_t* cbuf, const float (&x)[4
     wave_lds_fence();
 }
 
-// ------------------------------------------------------------------------------------------------
-// k_encrypt — K-PKE.Encrypt (ml_kem.c:776-936) given A^T (sampler, XOF role) and the PRF bytes (PRF role).
-//   COMPARE = false : write c                                   (Encaps_internal, ml_kem.c:1127)
-//   COMPARE = true  : compare c' with c, K = (c == c') ? K' : Kbar (Decaps_internal, ml_kem.c:1206-1215)
-// ------------------------------------------------------------------------------------------------
-template <int K, int ETA1, int DU, int DV, bool COMPARE>
-__global__ void __launch_bounds__(WAVE * ARITH_WAVES, arith_minwaves(K))
-k_encrypt(size_t n, const uint8_t* __restrict__ ek, size_t ek_stride, const uint8_t* __restrict__ msg, const uint16_t* __restrict__ A,
-          const uint8_t* __restrict__ prf, uint8_t* __restrict__ c_out, const uint8_t* __restrict__ c_in, const uint8_t* __restrict__ Kp,
-          const uint8_t* __restrict__ Kbar, uint8_t* __restrict__ Kout, int32_t* __restrict__ mod_status, size_t a_stride) {
-    // a_stride: uint16 elements between the matrices of consecutive items (K*K*256), or 0 when every item uses the same
-    // key and therefore the same matrix (shared-key batches: ek_stride is 0 as well)
-    // mod_status (optional): per-item result of the FIPS 203 encapsulation-key modulus check, 0 or -4.  The reference's
-    // own check can never fail (ml_kem.c:1273-1291, F3), so its callers pass nullptr.
-    __shared__ ArithLds<K> lds_all[ARITH_WAVES];
-    const int wv = wave_id(), l = lane_id();
-    const size_t item = (size_t)blockIdx.x * ARITH_WAVES + wv;
-    if (item >= n) return;
-    ArithLds<K>& L = lds_all[wv];
-    constexpr unsigned PS = (ETA1 == 3) ? 192 : 128, CLEN = 32 * (DU * K + DV);
-    const uint8_t* my_prf = prf + item * (size_t)((2 * K + 1) * PS);
-    const uint8_t* my_ek = ek + item * ek_stride;
-    const uint16_t* my_A = A + item * a_stride;
-    uint8_t* my_c = COMPARE ? nullptr : c_out + item * CLEN;
-    const uint8_t* my_cin = COMPARE ? c_in + item * CLEN : nullptr;
-
-    // ---- prologue: the loads the first phases need (PRF bytes, row 0 of A^T, message bits); the packed t-hat row and the
-    //      reference ciphertext rows follow one matrix row ahead of their use (fewer live registers: 6 waves per SIMD) ----
-    uint32_t raw_y[K], raw_e1[K], raw_e2;
-#pragma unroll
-    for (int b = 0; b < K; b++) raw_y[b] = cbd_load<ETA1>(my_prf + b * PS);
-    uint2 a_next[K];
-#pragma unroll
-    for (int b = 0; b < K; b++) a_next[b] = load_poly_raw(my_A + b * 256);   // row 0 of A^T
-#pragma unroll
-    for (int a = 0; a < K; a++) raw_e1[a] = cbd_load<2>(my_prf + (K + a) * PS);
-    raw_e2 = cbd_load<2>(my_prf + (2 * K) * PS);
-    const unsigned mb = msg[item * 32 + (l >> 1)] >> (4 * (l & 1));   // the lane's 4 message bits
-    CodecRegs<DU> cu_ref;   // the ciphertext row the current u row is compared with (fetched one row ahead)
-    CodecRegs<DV> cv_ref;
-    if constexpr (COMPARE) codec_fetch<DU>(my_cin, cu_ref);
-    NttTwiddlesF tw;
-    load_twiddles_f(tw);
-
-    uint32_t diff = 0;
-    float x[4];
-    CodecRegs<12> that[K];
-    // y-hat = NTT(CBD_eta1(PRF(r, n)))  n = 0..K-1   (ml_kem.c:826-836)
-#pragma unroll
-    for (int b = 0; b < K; b++) {
-        cbd_eval_f<ETA1>(raw_y[b], x);
-        wave_ntt_f(x, L.xch, tw);
-#pragma unroll
-        for (int m = 0; m < 4; m++) x[m] = fred(x[m]);
-        stash_vhat_f(L.vhat[b], L.vgam[b], x, tw);
-    }
-    wave_lds_fence();
-    // u[a] = InverseNTT(sum_b A^T[a][b] o y-hat[b]) + e1[a]  ->  Compress_du, ByteEncode_du   (ml_kem.c:854-896)
-#pragma unroll
-    for (int a = 0; a < K; a++) {
-        uint2 a_cur[K];
-#pragma unroll
-        for (int b = 0; b < K; b++) a_cur[b] = a_next[b];
-        if (a + 1 < K) {
-#pragma unroll
-            for (int b = 0; b < K; b++) a_next[b] = load_poly_raw(my_A + ((a + 1) * K + b) * 256);   // prefetch the next row
-        }
-        float acc[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int b = 0; b < K; b++) {
-            float av[4];
-            poly_raw_to_f(a_cur[b], av);
-            basemul_acc_f(acc, av, L.vhat[b], L.vgam[b]);
-        }
-        wave_intt_f(acc, L.xch, tw);
-        float e[4];
-        cbd_eval_f<2>(raw_e1[a], e);
-#pragma unroll
-        for (int m = 0; m < 4; m++) acc[m] += e[m];
-        diff |= emit_compressed<DU, COMPARE>(L.cbuf(), acc, COMPARE ? nullptr : my_c + a * 32 * DU, cu_ref);
-        if constexpr (COMPARE) {
-            if (a + 1 < K) codec_fetch<DU>(my_cin + (a + 1) * 32 * DU, cu_ref);
-            else codec_fetch<DV>(my_cin + K * 32 * DU, cv_ref);
-        }
-        if (a == K - 2 || K == 1) {   // t-hat is needed after the last row: fetch it one row ahead
-#pragma unroll
-            for (int b = 0; b < K; b++) codec_fetch<12>(my_ek + 384 * b, that[b]);
-        }
-    }
-    // v = InverseNTT(t-hat . y-hat) + e2 + Decompress_1(m)  ->  Compress_dv, ByteEncode_dv   (ml_kem.c:867-904)
-    {
-        float acc[4] = {0.f, 0.f, 0.f, 0.f};
-        bool over = false;
-#pragma unroll
-        for (int b = 0; b < K; b++) {
-            float tv[4];
-            decode_regs<12, false>(L.cbuf(), that[b], tv);   // raw 12-bit values (F3)
-#pragma unroll
-            for (int m = 0; m < 4; m++) over = over || (tv[m] >= F_Q);
-            basemul_acc_f(acc, tv, L.vhat[b], L.vgam[b]);
-        }
-        if (mod_status) {
-            const bool bad = __ballot(over) != 0;
-            if (l == 0) mod_status[item] = bad ? -4 : 0;
-        }
-        wave_intt_f(acc, L.xch, tw);
-        float e[4];
-        cbd_eval_f<2>(raw_e2, e);
-#pragma unroll
-        for (int m = 0; m < 4; m++) acc[m] += e[m] + (((mb >> m) & 1u) ? 1665.0f : 0.0f);   // Decompress_1(1) = 1665
-        diff |= emit_compressed<DV, COMPARE>(L.cbuf(), acc, COMPARE ? nullptr : my_c + K * 32 * DU, cv_ref);
-    }
-    if constexpr (COMPARE) {
-        // both candidates are read and blended by mask: neither a branch nor an address depends on whether the
-        // ciphertext matched (the reference's early-exit compare, ml_kem.c:1206-1215, leaks it; implicit rejection
-        // is meant to hide it)
-        const uint32_t reject = __ballot(diff != 0) != 0 ? 0xFFFFFFFFu : 0u;
-        if (l < 8) {
-            const uint32_t kp = reinterpret_cast<const uint32_t*>(Kp + item * 32)[l];
-            const uint32_t kb = reinterpret_cast<const uint32_t*>(Kbar + item * 32)[l];
-            reinterpret_cast<uint32_t*>(Kout + item * 32)[l] = (kp & ~reject) | (kb & reject);
-        }
-    }
-}
-
-// K-PKE.Decrypt (ml_kem.c:942-1023) lives in mlkem_kpke4.hpp: four items per wave, all in registers.
-
-// ------------------------------------------------------------------------------------------------
-// k_keygen — K-PKE.KeyGen after G and sampling (ml_kem.c:696-756) + the plain copies of KeyGen_internal
-// (ml_kem.c:1054-1062): ek = Enc12(t-hat) || rho ; dk = Enc12(s-hat) || ek || [H(ek)] || [z]
-// ------------------------------------------------------------------------------------------------
-// KEM_DK = true : dk rows are the ML-KEM decapsulation keys (768k+96 bytes: ŝ ‖ ek ‖ H(ek) ‖ z; this kernel fills ŝ ‖ ek)
-// KEM_DK = false: K-PKE.KeyGen on its own (ml_kem.c:651-769): dk rows are the 384k bytes of ŝ only
-template <int K, int ETA1, bool KEM_DK>
-__global__ void __launch_bounds__(WAVE * ARITH_WAVES, arith_minwaves(K))
-k_keygen(size_t n, const uint16_t* __restrict__ A, const uint8_t* __restrict__ prf, const uint8_t* __restrict__ rho,
-         uint8_t* __restrict__ ek, uint8_t* __restrict__ dk) {
-    __shared__ ArithLds<K> lds_all[ARITH_WAVES];
-    const int wv = wave_id(), l = lane_id();
-    const size_t item = (size_t)blockIdx.x * ARITH_WAVES + wv;
-    if (item >= n) return;
-    ArithLds<K>& L = lds_all[wv];
-    constexpr unsigned PS = (ETA1 == 3) ? 192 : 128, EK = 384 * K + 32, DK = KEM_DK ? 768 * K + 96 : 384 * K;
-    const uint8_t* my_prf = prf + item * (size_t)(2 * K * PS);
-    const uint16_t* my_A = A + item * (size_t)(K * K * 256);
-    uint8_t* my_ek = ek + item * EK;
-    uint8_t* my_dk = dk + item * DK;
-    uint32_t raw_s[K], raw_e[K];
-#pragma unroll
-    for (int b = 0; b < K; b++) raw_s[b] = cbd_load<ETA1>(my_prf + b * PS);
-    uint2 a_next[K];
-#pragma unroll
-    for (int b = 0; b < K; b++) a_next[b] = load_poly_raw(my_A + b * 256);
-#pragma unroll
-    for (int a = 0; a < K; a++) raw_e[a] = cbd_load<ETA1>(my_prf + (K + a) * PS);
-    const uint32_t rho_w = reinterpret_cast<const uint32_t*>(rho + item * 32)[l & 7];
-    NttTwiddlesF tw;
-    load_twiddles_f(tw);
-    float x[4];
-    // s-hat (ml_kem.c:696-706), dk_pke = ByteEncode_12(s-hat) (ml_kem.c:750-756)
-#pragma unroll
-    for (int b = 0; b < K; b++) {
-        cbd_eval_f<ETA1>(raw_s[b], x);
-        wave_ntt_f(x, L.xch, tw);
-#pragma unroll
-        for (int m = 0; m < 4; m++) x[m] = fred(x[m]);
-        stash_vhat_f(L.vhat[b], L.vgam[b], x, tw);
-        emit_encode12(L.cbuf(), x, my_dk + 384 * b, nullptr);
-    }
-    wave_lds_fence();
-    // t-hat[a] = sum_b A[a][b] o s-hat[b] + e-hat[a] (ml_kem.c:710-727), ek = ByteEncode_12(t-hat) || rho
-#pragma unroll
-    for (int a = 0; a < K; a++) {
-        uint2 a_cur[K];
-#pragma unroll
-        for (int b = 0; b < K; b++) a_cur[b] = a_next[b];
-        if (a + 1 < K) {
-#pragma unroll
-            for (int b = 0; b < K; b++) a_next[b] = load_poly_raw(my_A + ((a + 1) * K + b) * 256);
-        }
-        float acc[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int b = 0; b < K; b++) {
-            float av[4];
-            poly_raw_to_f(a_cur[b], av);
-            basemul_acc_f(acc, av, L.vhat[b], L.vgam[b]);
-        }
-        float e[4];
-        cbd_eval_f<ETA1>(raw_e[a], e);
-        wave_ntt_f(e, L.xch, tw);
-#pragma unroll
-        for (int m = 0; m < 4; m++) acc[m] += e[m];   // <= 1665 + 6660
-        emit_encode12(L.cbuf(), acc, my_ek + 384 * a, KEM_DK ? my_dk + 384 * K + 384 * a : (uint8_t*)nullptr);
-    }
-    if (l < 8) {
-        reinterpret_cast<uint32_t*>(my_ek + 384 * K)[l] = rho_w;
-        if (KEM_DK) reinterpret_cast<uint32_t*>(my_dk + 768 * K)[l] = rho_w;
-    }
-}
-
 // ================================================================================================
 // stand-alone primitives (C-ABI: mlkem_ntt / mlkem_intt / mlkem_multiply_ntts / mlkem_sample_cbd)
 // ================================================================================================
@@ -364,8 +125,7 @@ __global__ void __launch_bounds__(WAVE * ARITH_WAVES) k_basemul_batch(size_t n, 
     __shared__ __attribute__((aligned(16))) float vh_all[ARITH_WAVES][256];
     __shared__ __attribute__((aligned(16))) float vg_all[ARITH_WAVES][128];
     const int wv = (int)(threadIdx.x >> 6);
-    NttTwiddlesF tw;
-    load_twiddles_f(tw);
+    const Tw fD = ZETA_F.z[64 + lane_id()];   // gamma of the lane's pairs = +-zeta_{64 + lane}
     const size_t stride = (size_t)gridDim.x * ARITH_WAVES;
     for (size_t p = (size_t)blockIdx.x * ARITH_WAVES + wv; p < n; p += stride) {
         float av[4], bv[4], acc[4] = {0.f, 0.f, 0.f, 0.f};
@@ -373,7 +133,7 @@ __global__ void __launch_bounds__(WAVE * ARITH_WAVES) k_basemul_batch(size_t n, 
         load_poly_nat_f12(b + p * 256, bv);
 #pragma unroll
         for (int m = 0; m < 4; m++) bv[m] = fred(bv[m]);
-        stash_vhat_f(vh_all[wv], vg_all[wv], bv, tw);
+        stash_vhat_f(vh_all[wv], vg_all[wv], bv, fD);
         wave_lds_fence();
         basemul_acc_f(acc, av, vh_all[wv], vg_all[wv]);
         wave_lds_fence();
@@ -392,8 +152,7 @@ __global__ void __launch_bounds__(WAVE * ARITH_WAVES) k_vecmul_batch(size_t n, i
     __shared__ __attribute__((aligned(16))) float vh_all[ARITH_WAVES][256];
     __shared__ __attribute__((aligned(16))) float vg_all[ARITH_WAVES][128];
     const int wv = (int)(threadIdx.x >> 6);
-    NttTwiddlesF tw;
-    load_twiddles_f(tw);
+    const Tw fD = ZETA_F.z[64 + lane_id()];   // gamma of the lane's pairs = +-zeta_{64 + lane}
     const size_t stride = (size_t)gridDim.x * ARITH_WAVES;
     for (size_t p = (size_t)blockIdx.x * ARITH_WAVES + wv; p < n; p += stride) {
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
@@ -403,7 +162,7 @@ __global__ void __launch_bounds__(WAVE * ARITH_WAVES) k_vecmul_batch(size_t n, i
             load_poly_nat_f12(v + (p * (size_t)k + (size_t)i) * 256, bv);
 #pragma unroll
             for (int m = 0; m < 4; m++) bv[m] = fred(bv[m]);
-            stash_vhat_f(vh_all[wv], vg_all[wv], bv, tw);
+            stash_vhat_f(vh_all[wv], vg_all[wv], bv, fD);
             wave_lds_fence();
             basemul_acc_f(acc, av, vh_all[wv], vg_all[wv]);   // acc stays reduced: |acc| <= 1665
             wave_lds_fence();

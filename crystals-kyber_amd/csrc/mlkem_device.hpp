@@ -3,10 +3,10 @@
 // Everything here is wave64-native:
 //   * Keccak-f[1600] is lane-sliced (one sponge per lane, 25 lanes x 2 x u32 VGPRs) and built from
 //     v_bitop3_b32 (3-input LUT: xor3 for theta, a^(~b&c) for chi) and v_alignbit_b32 (64-bit rotates).
-//   * NTT / InverseNTT (mlkem_fntt.hpp) run one polynomial per wavefront, 4 coefficients per lane, radix-4
-//     register stages with the three cross-lane re-layouts staged through wave-private LDS; the mod-3329
-//     arithmetic is exact (integers < 2^24 on the fp32 pipe, Barrett reduction by reciprocal multiply), so
-//     results are canonical in [0, q) and bit-identical to the reference's `% Q` arithmetic (ml_kem.c:287-442).
+//   * NTT / InverseNTT run two items per wavefront through LDS inside K-PKE.KeyGen / Encrypt (mlkem_kpke2.hpp) and four
+//     polynomials per wavefront in registers with DPP butterflies elsewhere (mlkem_rntt.hpp), always on float2 pairs; the
+//     mod-3329 arithmetic is exact (integers < 2^24 on the fp32 pipe, Barrett reduction by reciprocal multiply, mlkem_fntt.hpp),
+//     so results are canonical in [0, q) and bit-identical to the reference's `% Q` arithmetic (ml_kem.c:287-442).
 //
 // Reference behaviour that is reproduced on purpose: PRF and J are SHAKE128
 // (ml_kem.c:508, :546), ByteDecode_12 does not reduce mod q (ml_kem.c:170).
@@ -248,31 +248,6 @@ __device__ __forceinline__ void lds_dma_wait() {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
 }
-
-// ----------------------------------------------------------------------------------------------
-// Coefficient layouts of the one-polynomial-per-wave NTT (mlkem_fntt.hpp).  Lane l holds 4 coefficients x[0..3]:
-//   NAT : c[4l + m]                      (contiguous; = basemul pair layout and HBM layout; layer len = 2)
-//   LA  : c[l + 64 m]                    (layers len = 128, 64 in registers)
-//   LB  : c[64 (l/16) + (l%16) + 16 m]   (len = 32, 16)
-//   LC  : c[16 (l/4)  + (l%4)  +  4 m]   (len = 8, 4)
-// ----------------------------------------------------------------------------------------------
-// The exchange buffer is addressed through an XOR swizzle so that all four access patterns are bank-conflict free
-// for ds_read_b32 / ds_write_b32 (32 banks, two 32-lane groups): index bits 3..2 ^= bits 6..5, bit 4 ^= bit 6.
-// Bits 1..0 are untouched, so a lane's 4 consecutive NAT coefficients stay one aligned 16-byte slot.
-#ifndef MLKEM_XCH_SWIZZLE
-#define MLKEM_XCH_SWIZZLE 1
-#endif
-__device__ __forceinline__ int xch_swz(int i) {
-#if MLKEM_XCH_SWIZZLE
-    return i ^ (((i >> 5) & 3) << 2) ^ (((i >> 6) & 1) << 4);
-#else
-    return i;
-#endif
-}
-__device__ __forceinline__ int idx_NAT(int l) { return xch_swz(4 * l); }
-__device__ __forceinline__ int idx_LA(int l, int m) { return xch_swz(l + 64 * m); }
-__device__ __forceinline__ int idx_LB(int l, int m) { return xch_swz(64 * (l >> 4) + (l & 15) + 16 * m); }
-__device__ __forceinline__ int idx_LC(int l, int m) { return xch_swz(16 * (l >> 2) + (l & 3) + 4 * m); }
 
 // ----------------------------------------------------------------------------------------------
 // bit-packed codecs (ml_kem.c:125-177) through a wave-private LDS byte buffer.

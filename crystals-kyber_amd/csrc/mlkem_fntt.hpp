@@ -1,5 +1,5 @@
-// mlkem_fntt.hpp — one-polynomial-per-wave NTT / InverseNTT / base-case multiply with EXACT arithmetic on the
-// fp32 pipe (ml_kem.c:287-442).
+// mlkem_fntt.hpp — EXACT mod-3329 arithmetic on the fp32 pipe: the reduction, twiddle product, canonicalisation, Compress and
+// base-case-multiply helpers every transform and K-PKE kernel is built from (ml_kem.c:83-97, :287-442), and the zeta table.
 //
 // Why fp32: on gfx950 every integer multiply (v_mul_*_i24/u24, v_mul_lo_u32, v_mad_*24), shift and bit-field op
 // issues at ~0.55x the rate of v_fma_f32 / v_mul_f32 / v_add_f32 (tools/valu_ubench2.hip, profiles/r01_valu_ubench.txt).
@@ -40,10 +40,8 @@ __device__ __forceinline__ float fmulmod_shoup(Tw w, float b) {
     const float nkq = __builtin_fmaf(km, -F_Q, F_MAGIC_Q);
     return __builtin_fmaf(b, w.z, nkq);
 }
-// Which product where (measured on MI355X, DESIGN.md section 4, profiles/r03_kpke_experiments.txt): a twiddle that is a
-// compile-time constant or sits in a register pair anyway takes the 3-FMA form (fmulmod_shoup: the register transforms of
-// mlkem_rntt.hpp, the two outermost layers here); the per-lane twiddles of the LDS transforms take mul + Barrett, because
-// carrying their quotient halves costs 10-18 VGPRs of a kernel that lives on occupancy.
+// mul + Barrett form of the same product (4 instead of 3 operations, no quotient half needed); the transforms use the 3-FMA
+// form, the stand-alone base-case products this one.
 __device__ __forceinline__ float fmulmod(Tw w, float b) { return fred(w.z * b); }
 constexpr Tw tw_const(int zeta_centred) { return Tw{(float)zeta_centred, (float)((double)zeta_centred / 3329.0)}; }
 __device__ __forceinline__ Tw tw_neg(Tw w) { return Tw{-w.z, -w.zq}; }
@@ -90,60 +88,13 @@ struct ZetaTableF {
 };
 __device__ const ZetaTableF ZETA_F = ZetaTableF();   // zeta_i = 17^BitRev7(i) mod q, centred (ml_kem.c:300-307)
 
-struct NttTwiddlesF {
-    Tw fB0, fB1, fB2, fC0, fC1, fC2, fD;   // forward: see NttTwiddles in mlkem_device.hpp for the index map
-    Tw iD, iC0, iC1, iC2, iB0, iB1, iB2;   // inverse
-};
-__device__ __forceinline__ void load_twiddles_f(NttTwiddlesF& t) {
-    const int l = lane_id(), blk = l >> 4, b16 = l >> 2;
-    const Tw* z = ZETA_F.z;
-    t.fB0 = z[4 + blk]; t.fB1 = z[8 + 2 * blk]; t.fB2 = z[9 + 2 * blk];
-    t.fC0 = z[16 + b16]; t.fC1 = z[32 + 2 * b16]; t.fC2 = z[33 + 2 * b16];
-    t.fD = z[64 + l];
-    t.iD = z[127 - l];
-    t.iC0 = z[63 - 2 * b16]; t.iC1 = z[62 - 2 * b16]; t.iC2 = z[31 - b16];
-    t.iB0 = z[15 - 2 * blk]; t.iB1 = z[14 - 2 * blk]; t.iB2 = z[7 - blk];
-}
 constexpr Tw FZ1 = tw_const(cx_centered(cx_pow17(cx_bitrev7(1))));
 constexpr Tw FZ2 = tw_const(cx_centered(cx_pow17(cx_bitrev7(2))));
 constexpr Tw FZ3 = tw_const(cx_centered(cx_pow17(cx_bitrev7(3))));
 constexpr Tw F_INV128 = tw_const(INV128 - KQ);   // 128^-1 = 3303 = -26 mod q (ml_kem.c:378-381)
 constexpr Tw F_INV128_Z1 = tw_const(cx_centered((INV128 * cx_pow17(cx_bitrev7(1))) % KQ));   // zeta_1 / 128 mod q
 
-// Cooley-Tukey (ml_kem.c:311-324): a' = a + zeta b, b' = a - zeta b ; bounds grow by 1665 per layer
-__device__ __forceinline__ void ct_bfly_f(float& a, float& b, Tw zeta) {
-    const float t = fmulmod(zeta, b);
-    b = a - t;
-    a = a + t;
-}
-// the same with a COMPILE-TIME twiddle (the two outermost layers and the final scaling): zeta and zeta/q are literals, so
-// the 3-FMA product costs no registers and is one instruction shorter than mul + Barrett
-__device__ __forceinline__ void ct_bfly_c(float& a, float& b, Tw zeta) {
-    const float t = fmulmod_shoup(zeta, b);
-    b = a - t;
-    a = a + t;
-}
-__device__ __forceinline__ void gs_bfly_c(float& a, float& b, Tw zeta) {
-    const float t = a;
-    a = t + b;
-    b = fmulmod_shoup(zeta, b - t);
-}
-// Gentleman-Sande (ml_kem.c:359-373): a' = a + b, b' = zeta (b - a)
-__device__ __forceinline__ void gs_bfly_f(float& a, float& b, Tw zeta) {
-    const float t = a;
-    a = t + b;
-    b = fmulmod(zeta, b - t);
-}
-
-#define MLKEM_FX_WRITE(IDX)                                                       \
-    {                                                                             \
-        _Pragma("unroll") for (int m = 0; m < 4; m++) xch[IDX(l, m)] = x[m];      \
-    }
-#define MLKEM_FX_READ(IDX)                                                        \
-    {                                                                             \
-        _Pragma("unroll") for (int m = 0; m < 4; m++) x[m] = xch[IDX(l, m)];      \
-    }
-// 4 consecutive coefficients of lane l as one 16-byte access: `slot` = 4l (linear buffers) or idx_NAT(l) (exchange buffer)
+// 4 consecutive coefficients of lane l as one 16-byte LDS access
 __device__ __forceinline__ void fx_write4(float* buf, int slot, const float (&x)[4]) {
     float4 v;
     v.x = x[0]; v.y = x[1]; v.z = x[2]; v.w = x[3];
@@ -154,92 +105,15 @@ __device__ __forceinline__ void fx_read4(const float* buf, int slot, float (&x)[
     x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w;
 }
 
-// Forward NTT (ml_kem.c:287-329).  In: NAT layout, |x| <= 3328.  Out: NAT layout, |x| <= 6663 (lazy).
-// `xch` = 256 floats of wave-private LDS.
-// wave_ntt_la_f takes the input already in LA layout (x[m] = c[l + 64 m]) and skips the first exchange.
-__device__ __forceinline__ void wave_ntt_la_f(float (&x)[4], float* xch, const NttTwiddlesF& tw);
-__device__ __forceinline__ void wave_ntt_f(float (&x)[4], float* xch, const NttTwiddlesF& tw) {
-    const int l = lane_id();
-    fx_write4(xch, idx_NAT(l), x);
-    wave_lds_fence();
-    MLKEM_FX_READ(idx_LA)
-    wave_lds_fence();
-    wave_ntt_la_f(x, xch, tw);
-}
-__device__ __forceinline__ void wave_ntt_la_f(float (&x)[4], float* xch, const NttTwiddlesF& tw) {
-    const int l = lane_id();
-    ct_bfly_c(x[0], x[2], FZ1); ct_bfly_c(x[1], x[3], FZ1);          // len 128 : <= 3328 + 1665
-    ct_bfly_c(x[0], x[1], FZ2); ct_bfly_c(x[2], x[3], FZ3);          // len 64  : <= 3328 + 2*1665
-    wave_lds_fence();
-    MLKEM_FX_WRITE(idx_LA)
-    wave_lds_fence();
-    MLKEM_FX_READ(idx_LB)
-    ct_bfly_f(x[0], x[2], tw.fB0); ct_bfly_f(x[1], x[3], tw.fB0);    // len 32
-    ct_bfly_f(x[0], x[1], tw.fB1); ct_bfly_f(x[2], x[3], tw.fB2);    // len 16  : <= 3328 + 4*1665 = 9988 (< 10082)
-#pragma unroll
-    for (int m = 0; m < 4; m++) x[m] = fred(x[m]);                    // <= 1665
-    wave_lds_fence();
-    MLKEM_FX_WRITE(idx_LB)
-    wave_lds_fence();
-    MLKEM_FX_READ(idx_LC)
-    ct_bfly_f(x[0], x[2], tw.fC0); ct_bfly_f(x[1], x[3], tw.fC0);    // len 8
-    ct_bfly_f(x[0], x[1], tw.fC1); ct_bfly_f(x[2], x[3], tw.fC2);    // len 4   : <= 1665 + 2*1665
-    wave_lds_fence();
-    MLKEM_FX_WRITE(idx_LC)
-    wave_lds_fence();
-    fx_read4(xch, idx_NAT(l), x);
-    ct_bfly_f(x[0], x[2], tw.fD); ct_bfly_f(x[1], x[3], tw.fD);      // len 2   : <= 6660
-    wave_lds_fence();
-}
-
-// Inverse NTT (ml_kem.c:336-384) including the final multiplication by 128^-1.
-// In: NAT layout, |x| <= 2520.  Out: NAT layout, |x| <= 1665 (centred).
-// Two lazy Gentleman-Sande layers per register stage need inputs <= 2520 (4 * 2520 <= 10082); after a stage the
-// two "sum path" values (x0 <= 4B, x1 <= 2B) are reduced before the exchange.
-__device__ __forceinline__ void wave_intt_f(float (&x)[4], float* xch, const NttTwiddlesF& tw) {
-    const int l = lane_id();
-    gs_bfly_f(x[0], x[2], tw.iD); gs_bfly_f(x[1], x[3], tw.iD);      // len 2 : sums <= 5040, products <= 1665
-    x[0] = fred(x[0]); x[1] = fred(x[1]);
-    fx_write4(xch, idx_NAT(l), x);
-    wave_lds_fence();
-    MLKEM_FX_READ(idx_LC)
-    gs_bfly_f(x[0], x[1], tw.iC0); gs_bfly_f(x[2], x[3], tw.iC1);    // len 4
-    gs_bfly_f(x[0], x[2], tw.iC2); gs_bfly_f(x[1], x[3], tw.iC2);    // len 8 : x0 <= 6660, x1 <= 3330, x2, x3 <= 1665
-    x[0] = fred(x[0]); x[1] = fred(x[1]);
-    wave_lds_fence();
-    MLKEM_FX_WRITE(idx_LC)
-    wave_lds_fence();
-    MLKEM_FX_READ(idx_LB)
-    gs_bfly_f(x[0], x[1], tw.iB0); gs_bfly_f(x[2], x[3], tw.iB1);    // len 16
-    gs_bfly_f(x[0], x[2], tw.iB2); gs_bfly_f(x[1], x[3], tw.iB2);    // len 32
-    x[0] = fred(x[0]); x[1] = fred(x[1]);
-    wave_lds_fence();
-    MLKEM_FX_WRITE(idx_LB)
-    wave_lds_fence();
-    MLKEM_FX_READ(idx_LA)
-    gs_bfly_c(x[0], x[1], FZ3); gs_bfly_c(x[2], x[3], FZ2);          // len 64 : sums <= 3330
-#pragma unroll
-    for (int m = 0; m < 2; m++) {                                     // len 128 with the final x 128^-1 (ml_kem.c:378-381) folded in:
-        const float sum = x[m] + x[m + 2], dif = x[m + 2] - x[m];     //   a' = 128^-1 (a + b), b' = (zeta_1 128^-1)(b - a); |sum|, |dif| <= 6660
-        x[m] = fmulmod_shoup(F_INV128, sum);
-        x[m + 2] = fmulmod_shoup(F_INV128_Z1, dif);
-    }
-    wave_lds_fence();
-    MLKEM_FX_WRITE(idx_LA)
-    wave_lds_fence();
-    fx_read4(xch, idx_NAT(l), x);
-    wave_lds_fence();
-}
-
 // ---- base-case multiply-accumulate (ml_kem.c:395-442, :618-638) ------------------------------------------------
 // An NTT-domain polynomial v (reduced, |v| <= 1665) is kept in LDS together with its odd coefficients times gamma
 // (gamma_{2l} = zeta_{64+l}, gamma_{2l+1} = -gamma_{2l}).
-__device__ __forceinline__ void stash_vhat_f(float* vh, float* vg, const float (&x)[4], const NttTwiddlesF& tw) {
+__device__ __forceinline__ void stash_vhat_f(float* vh, float* vg, const float (&x)[4], const Tw fD) {
     const int l = lane_id();
     fx_write4(vh, 4 * l, x);
     float2 g;
-    g.x = fmulmod(tw.fD, x[1]);
-    g.y = fmulmod(tw_neg(tw.fD), x[3]);
+    g.x = fmulmod(fD, x[1]);
+    g.y = fmulmod(tw_neg(fD), x[3]);
     *reinterpret_cast<float2*>(vg + 2 * l) = g;
 }
 // acc = (acc + a o v) reduced : for 0 <= a <= 4095 (raw 12-bit, F3) and |v|, |acc| <= 1665 the exact sum is

@@ -627,4 +627,105 @@ k_encrypt2(size_t n, const uint8_t* __restrict__ ek, size_t ek_stride, const uin
     }
 }
 
+// canonical representatives in [0, q) of the lane's pairs (any |x| <= 2^24), as integers
+__device__ __forceinline__ void k2_canon(const v2f (&p)[4], unsigned (&c)[8]) {
+    v2f r[4] = {p[0], p[1], p[2], p[3]};
+    k2_fred_n<4>(r);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int a = (int)r[j].x, b = (int)r[j].y;
+        c[2 * j] = (unsigned)(a + ((a >> 31) & KQ));
+        c[2 * j + 1] = (unsigned)(b + ((b >> 31) & KQ));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_keygen2 — K-PKE.KeyGen after G and sampling (ml_kem.c:696-756) + the plain copies of KeyGen_internal
+// (ml_kem.c:1054-1062) for two items per wave: ek = Enc12(t-hat) || rho ; dk = Enc12(s-hat) || ek || [H(ek)] || [z]
+// Arguments as k_keygen (mlkem_arith.hpp).
+// ------------------------------------------------------------------------------------------------
+template <int K, int ETA1, bool KEM_DK>
+__global__ void __launch_bounds__(WAVE * KPKE2_WAVES, kpke2_minwaves(K))
+k_keygen2(size_t n, const uint16_t* __restrict__ A, const uint8_t* __restrict__ prf, const uint8_t* __restrict__ rho,
+          uint8_t* __restrict__ ek, uint8_t* __restrict__ dk) {
+    __shared__ K2Lds<K> lds_all[KPKE2_WAVES];
+    const int wv = wave_id(), l = lane_id(), h = l >> 5, t = l & 31;
+    const size_t item0 = 2 * ((size_t)blockIdx.x * KPKE2_WAVES + wv);
+    if (item0 >= n) return;
+    const bool valid = item0 + (size_t)h < n;
+    const unsigned hh = valid ? (unsigned)h : 0u;
+    float2 (*xch)[2][128] = lds_all[wv].xch;
+    constexpr unsigned PS = (ETA1 == 3) ? 192 : 128, EK = 384 * K + 32, DK = KEM_DK ? 768 * K + 96 : 384 * K, PRFLEN = 2 * K * PS;
+    const uint8_t* my_prf = prf + item0 * (size_t)PRFLEN + (size_t)(hh * PRFLEN);
+    const uint16_t* my_A = A + item0 * (size_t)(K * K * 256) + (size_t)(hh * (unsigned)(K * K * 256));
+    uint8_t* my_ek = ek + item0 * EK + (size_t)(hh * EK);
+    uint8_t* my_dk = dk + item0 * DK + (size_t)(hh * DK);
+    const size_t item = item0 + hh;
+
+    K2CbdRaw<ETA1> raw_s[K], raw_e[K];
+#pragma unroll
+    for (int b = 0; b < K; b++) k2_cbd_load_la<ETA1>(my_prf + b * PS, t, raw_s[b]);
+    uint4 a_next[K];
+#pragma unroll
+    for (int b = 0; b < K; b++) a_next[b] = *reinterpret_cast<const uint4*>(my_A + b * 256 + 8 * t);
+#pragma unroll
+    for (int a = 0; a < K; a++) k2_cbd_load_la<ETA1>(my_prf + (K + a) * PS, t, raw_e[a]);
+    const uint32_t rho_w = reinterpret_cast<const uint32_t*>(rho + item * 32)[t & 7];
+    K2Tw tw;
+    k2_twiddles_fwd(tw, t);
+    // s-hat (ml_kem.c:696-706), dk_pke = ByteEncode_12(s-hat) (ml_kem.c:750-756)
+    v2f sh[K][4];
+    float sg[K][4];
+#pragma unroll
+    for (int b = 0; b < K; b++) k2_cbd_eval<ETA1>(raw_s[b], sh[b]);
+    k2_ntt<K>(sh, xch, h, t, tw);
+#pragma unroll
+    for (int b = 0; b < K; b++) {
+        k2_fred_n<4>(sh[b]);
+        k2_gamma(sh[b], tw.d0, tw.d1, sg[b]);
+        unsigned c[8];
+        k2_canon(sh[b], c);
+        K2Piece<12> o;
+        k2_encode<12>(c, t, o);
+        if (valid) k2_piece_store<12>(my_dk + 384 * b, t, o);
+    }
+    // e-hat (ml_kem.c:710-716): lazy, |x| <= 3 + 7 * 1668
+    v2f eh[K][4];
+#pragma unroll
+    for (int a = 0; a < K; a++) k2_cbd_eval<ETA1>(raw_e[a], eh[a]);
+    k2_ntt<K>(eh, xch, h, t, tw);
+    // t-hat[a] = sum_b A[a][b] o s-hat[b] + e-hat[a] (ml_kem.c:717-727), ek = ByteEncode_12(t-hat) || rho
+#pragma unroll
+    for (int a = 0; a < K; a++) {
+        uint4 a_cur[K];
+#pragma unroll
+        for (int b = 0; b < K; b++) a_cur[b] = a_next[b];
+        if (a + 1 < K) {
+#pragma unroll
+            for (int b = 0; b < K; b++) a_next[b] = *reinterpret_cast<const uint4*>(my_A + ((a + 1) * K + b) * 256 + 8 * t);
+        }
+        v2f acc[4] = {splat2(0.f), splat2(0.f), splat2(0.f), splat2(0.f)};
+#pragma unroll
+        for (int b = 0; b < K; b++) {
+            v2f av[4];
+            k2_unpack16(a_cur[b], av);
+            k2_basemul_acc(acc, av, sh[b], sg[b]);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[j] = acc[j] + eh[a][j];   // <= 1665 + 11679
+        unsigned c[8];
+        k2_canon(acc, c);
+        K2Piece<12> o;
+        k2_encode<12>(c, t, o);
+        if (valid) {
+            k2_piece_store<12>(my_ek + 384 * a, t, o);
+            if constexpr (KEM_DK) k2_piece_store<12>(my_dk + 384 * K + 384 * a, t, o);
+        }
+    }
+    if (t < 8 && valid) {
+        reinterpret_cast<uint32_t*>(my_ek + 384 * K)[t] = rho_w;
+        if constexpr (KEM_DK) reinterpret_cast<uint32_t*>(my_dk + 768 * K)[t] = rho_w;
+    }
+}
+
 }   // namespace mlkem

@@ -161,17 +161,10 @@ inline void launch_sample(stream_t st, const ParamSet& p, size_t n, const uint8_
     launch_sample_split(st, p, n, n, rho, rho_stride, transpose, r, prf_per_item, n_eta1, ws);
 }
 
-// K-PKE.Encrypt launch: two items per wave with packed fp32 (mlkem_kpke2.hpp); MLKEM_KPKE2=0 builds the one-item-per-wave LDS
-// form of mlkem_arith.hpp instead (A/B)
-#ifndef MLKEM_KPKE2
-#define MLKEM_KPKE2 1
-#endif
+// K-PKE.Encrypt launch: two items per wave (mlkem_kpke2.hpp)
 template <int K, int ETA1, int DU, int DV, bool CMP, class... Args>
 inline void encrypt_launch(const char* label, stream_t st, size_t n, Args... args) {
-    if constexpr (MLKEM_KPKE2 != 0)
-        launch(label, k_encrypt2<K, ETA1, DU, DV, CMP>, ceil_div(ceil_div(n, 2), KPKE2_WAVES), WAVE * KPKE2_WAVES, st, n, args...);
-    else
-        launch(label, k_encrypt<K, ETA1, DU, DV, CMP>, ceil_div(n, ARITH_WAVES), WAVE * ARITH_WAVES, st, n, args...);
+    launch(label, k_encrypt2<K, ETA1, DU, DV, CMP>, ceil_div(ceil_div(n, 2), KPKE2_WAVES), WAVE * KPKE2_WAVES, st, n, args...);
 }
 
 // ---- ML-KEM.KeyGen_internal (ml_kem.c:1034-1084) ; z == nullptr: K-PKE.KeyGen alone (ml_kem.c:651-769, dk = 384k-byte ŝ) ----
@@ -186,14 +179,13 @@ inline void keygen_run(stream_t st, const ParamSet& p, size_t n, const uint8_t* 
         for (size_t c0 = 0; c0 < hn; c0 += ws.cap) {
             const size_t cn = min_sz(ws.cap, hn - c0), i0 = h0 + c0;
             launch_sample(st, p, cn, ws.rho + c0 * 32, 32, /*transpose=*/0, ws.r + c0 * 32, 2 * K, 2 * K, ws);
+            const size_t kgrid = ceil_div(ceil_div(cn, 2), KPKE2_WAVES);
             if (kem)
-                launch("k_keygen", k_keygen<K, ETA1, true>, ceil_div(cn, ARITH_WAVES), WAVE * ARITH_WAVES, st, cn,
-                       (const uint16_t*)ws.A, (const uint8_t*)ws.prf, (const uint8_t*)(ws.rho + c0 * 32), ek + i0 * p.ek_len,
-                       dk + i0 * dk_len);
+                launch("k_keygen", k_keygen2<K, ETA1, true>, kgrid, WAVE * KPKE2_WAVES, st, cn, (const uint16_t*)ws.A, (const uint8_t*)ws.prf,
+                       (const uint8_t*)(ws.rho + c0 * 32), ek + i0 * p.ek_len, dk + i0 * dk_len);
             else
-                launch("k_keygen", k_keygen<K, ETA1, false>, ceil_div(cn, ARITH_WAVES), WAVE * ARITH_WAVES, st, cn,
-                       (const uint16_t*)ws.A, (const uint8_t*)ws.prf, (const uint8_t*)(ws.rho + c0 * 32), ek + i0 * p.ek_len,
-                       dk + i0 * dk_len);
+                launch("k_keygen", k_keygen2<K, ETA1, false>, kgrid, WAVE * KPKE2_WAVES, st, cn, (const uint16_t*)ws.A, (const uint8_t*)ws.prf,
+                       (const uint8_t*)(ws.rho + c0 * 32), ek + i0 * p.ek_len, dk + i0 * dk_len);
         }
         if (kem)
             launch("k_hash_keygen_fin", k_hash_keygen_fin<K>, ceil_div(hn, WAVE), WAVE, st, hn, (const uint8_t*)(ek + h0 * p.ek_len),

@@ -14,9 +14,14 @@
 //                                                      and the accumulator pinned at each corner of their ranges
 //   sweep 6  fcanon(x), fcanon_floor(x)                every |x| <= 2^20 (outputs canonical in [0, q))
 //   sweep 7  fmulmod_shoup by 1 (the reduction of the cross-lane butterflies, mlkem_rntt.hpp)   every |x| <= 2^22
+//   sweep 8  the PACKED forms (v_pk_fma_f32 / v_pk_add_f32: mlkem_rntt.hpp, mlkem_kpke2.hpp) against the integer forms, both
+//            halves of every pair: fred2 every |x| <= 2^24 ; fmulmod_shoup2 over the 260 multipliers x every |b| <= 10082 ;
+//            k2_compress4<D>, D in {4, 5, 10, 11}, every |x| <= 4095 ; k2_canon every |x| <= 2^20 ;
+//            k2_basemul_acc at the corners of its bound over every (a0, y0)
 #pragma once
 #include "mlkem_arith.hpp"
 #include "mlkem_rntt.hpp"
+#include "mlkem_kpke2.hpp"
 
 namespace mlkem {
 
@@ -114,11 +119,60 @@ __global__ void __launch_bounds__(256) k_selftest(int sweep, unsigned long long*
             if (!centred_ok(fmulmod_shoup(TW_ONE, (float)x), x)) bad++;
         }
     }
+    else if (sweep == 8) {
+        // a pair carries (x, -x) or two neighbouring operands, so both halves of the packed instruction see the whole domain
+        for (long long i = (long long)tid; i <= (1ll << 24); i += (long long)nthreads) {
+            const v2f r = fred2(v2f{(float)i, (float)-i});
+            if (!centred_ok(r.x, i) || !centred_ok(r.y, -i)) bad++;
+        }
+        const long long per = 2 * 10082 + 1, total = 260 * per;
+        for (long long i = (long long)tid; i < total; i += (long long)nthreads) {
+            const int wi = (int)(i / per), b = (int)(i % per) - 10082;
+            Tw w = (wi >> 1) < 128 ? ZETA_F.z[wi >> 1] : (wi >> 1) == 128 ? F_INV128 : F_INV128_Z1;
+            if (wi & 1) w = tw_neg(w);
+            const v2f r = fmulmod_shoup2(w, v2f{(float)b, (float)-b});
+            if (!centred_ok(r.x, (long long)(int)w.z * b) || !centred_ok(r.y, -(long long)(int)w.z * b)) bad++;
+        }
+        for (long long i = (long long)tid; i <= 8190; i += (long long)nthreads) {
+            const int x = (int)i - 4095;
+            const v2f in[4] = {v2f{(float)x, (float)-x}, v2f{(float)x, (float)x}, v2f{(float)-x, (float)x}, v2f{0.f, (float)x}};
+            unsigned c[8];
+            k2_compress4<4>(in, c);
+            if (c[0] != compress_ref<4>(x) || c[1] != compress_ref<4>(-x) || c[2] != c[0] || c[3] != c[0] || c[4] != c[1] || c[7] != c[0]) bad++;
+            k2_compress4<5>(in, c);
+            if (c[0] != compress_ref<5>(x) || c[1] != compress_ref<5>(-x) || c[5] != c[0]) bad++;
+            k2_compress4<10>(in, c);
+            if (c[0] != compress_ref<10>(x) || c[1] != compress_ref<10>(-x) || c[3] != c[0]) bad++;
+            k2_compress4<11>(in, c);
+            if (c[0] != compress_ref<11>(x) || c[1] != compress_ref<11>(-x) || c[4] != c[1]) bad++;
+        }
+        for (long long i = (long long)tid; i <= (1ll << 20); i += (long long)nthreads) {
+            const v2f in[4] = {v2f{(float)i, (float)-i}, v2f{(float)-i, (float)i}, v2f{(float)i, (float)i}, v2f{0.f, (float)-i}};
+            unsigned c[8];
+            k2_canon(in, c);
+            const unsigned p = (unsigned)imod_q(i), m = (unsigned)imod_q(-i);
+            if (c[0] != p || c[1] != m || c[2] != m || c[3] != p || c[4] != p || c[5] != p || c[6] != 0u || c[7] != m) bad++;
+        }
+        const long long na = 4096, ny = 2 * 1665 + 1;
+        for (long long i = (long long)tid; i < na * ny * 8; i += (long long)nthreads) {
+            const int corner = (int)(i / (na * ny));
+            const long long r = i % (na * ny);
+            const int a0 = (int)(r / ny), y0 = (int)(r % ny) - 1665;
+            const int a1 = (corner & 1) ? 4095 : 0, g = (corner & 2) ? 1665 : -1665, ac = (corner & 4) ? 1665 : -1665;
+            // pair j: (acc0, acc1) + (a0, a1) o (y0, y1) with y1 * gamma = g:  c0 = a0 y0 + a1 g + acc ; c1 = a0 y1 + a1 y0 + acc
+            v2f acc[4], a[4], y[4];
+            float yg[4];
+            for (int j = 0; j < 4; j++) { acc[j] = v2f{(float)ac, (float)ac}; a[j] = v2f{(float)a0, (float)a1}; y[j] = v2f{(float)y0, (float)g}; yg[j] = (float)g; }
+            k2_basemul_acc(acc, a, y, yg);
+            const long long e0 = (long long)a0 * y0 + (long long)a1 * g + ac, e1 = (long long)a0 * g + (long long)a1 * y0 + ac;
+            if (!centred_ok(acc[0].x, e0) || !centred_ok(acc[0].y, e1) || !centred_ok(acc[3].x, e0) || !centred_ok(acc[3].y, e1)) bad++;
+        }
+    }
     // one atomic per wave
     for (int off = 32; off > 0; off >>= 1) bad += __shfl_xor(bad, off);
     if ((threadIdx.x & 63) == 0 && bad) atomicAdd(bad_out, bad);
 }
 
-constexpr int SELFTEST_SWEEPS = 8;
+constexpr int SELFTEST_SWEEPS = 9;
 
 }   // namespace mlkem

@@ -53,8 +53,8 @@ def test_fp32_arithmetic_exhaustive_on_device(pkg, eng):
     over |x| <= 4095; cbd_eval_f<2> / <3> over all 2^16 / 2^24 lane inputs; the base-case multiply-accumulate at the corners
     of its bound over every (a, y); canonicalisation over |x| <= 2^20 -- each against integer `% q` arithmetic computed on
     the device (ml_kem.c:83-97, :253-275, :287-442).  Zero violations."""
-    assert pkg.load_library().mlkem_selftest_count() == 8
-    assert eng.selftest() == [0] * 8
+    assert pkg.load_library().mlkem_selftest_count() == 9
+    assert eng.selftest() == [0] * 9
 
 
 def test_selftest_counter_actually_counts(pkg, eng):
