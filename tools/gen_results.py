@@ -37,8 +37,10 @@ def short(kernel_name):
     if not m:
         return base
     name, targs = m.group(1), m.group(2)
-    if name == "k_encrypt":
+    if name in ("k_encrypt", "k_encrypt2"):
         return "k_encrypt_cmp" if re.search(r",\s*true$", targs) else "k_encrypt"
+    if name == "k_keygen2":
+        return "k_keygen"
     if name == "k_ntt4_batch":
         return "k_intt_batch" if targs == "true" else "k_ntt_batch"
     if name == "k_decrypt4":

@@ -50,11 +50,17 @@ def label_of(kernel_name):
     short = re.sub(r"^void ", "", kernel_name).replace("mlkem::", "")
     base = short.split("<")[0].split("(")[0]
     if base == "k_sample":
-        return "k_sample_tail", short
+        return "k_sample_restart", short
     if base == "k_ntt4_batch":
         return ("k_intt_batch" if "<true>" in short else "k_ntt_batch"), short
-    if base == "k_encrypt":
+    if base in ("k_encrypt", "k_encrypt2"):
         return ("k_encrypt_cmp" if re.search(r",\s*true>", short) else "k_encrypt"), short
+    if base == "k_keygen2":
+        return "k_keygen", short
+    if base == "k_decrypt4":
+        return "k_decrypt", short
+    if base == "k_sample_resume":
+        return "k_sample_tail", short
     return base, short
 
 
