@@ -17,7 +17,8 @@
 //   sweep 8  the PACKED forms (v_pk_fma_f32 / v_pk_add_f32: mlkem_rntt.hpp, mlkem_kpke2.hpp) against the integer forms, both
 //            halves of every pair: fred2 every |x| <= 2^24 ; fmulmod_shoup2 over the 260 multipliers x every |b| <= 10082 ;
 //            k2_compress4<D>, D in {4, 5, 10, 11}, every |x| <= 4095 ; k2_canon every |x| <= 2^20 ;
-//            k2_basemul_acc at the corners of its bound over every (a0, y0)
+//            k2_basemul_acc at the corners of its bound over every (a0, y0) ; k2_cbd2_eval8 over every 16-bit half pattern in
+//            both halves of the dword (a nibble's result does not depend on the other nibbles: 2^16 x 2 positions x 3 fillers)
 #pragma once
 #include "mlkem_arith.hpp"
 #include "mlkem_rntt.hpp"
@@ -152,6 +153,19 @@ __global__ void __launch_bounds__(256) k_selftest(int sweep, unsigned long long*
             k2_canon(in, c);
             const unsigned p = (unsigned)imod_q(i), m = (unsigned)imod_q(-i);
             if (c[0] != p || c[1] != m || c[2] != m || c[3] != p || c[4] != p || c[5] != p || c[6] != 0u || c[7] != m) bad++;
+        }
+        for (long long i = (long long)tid; i < (1ll << 16) * 6; i += (long long)nthreads) {
+            const uint32_t v = (uint32_t)(i & 0xFFFF), fill = (uint32_t)((i >> 16) % 3) * 0x5A5Au + ((i >> 16) % 3 == 2 ? 0xFFFFu - 2 * 0x5A5Au : 0u);
+            const bool upper = (i >> 16) >= 3;
+            const uint32_t t = upper ? (v << 16) | fill : v | (fill << 16);
+            v2f p[4];
+            k2_cbd2_eval8(t, p);
+            const float got[8] = {p[0].x, p[0].y, p[1].x, p[1].y, p[2].x, p[2].y, p[3].x, p[3].y};
+            for (int c = 0; c < 8; c++) {
+                const uint32_t nib = (t >> (4 * c)) & 0xFu;
+                const int want = (int)((nib & 1u) + ((nib >> 1) & 1u)) - (int)(((nib >> 2) & 1u) + ((nib >> 3) & 1u));
+                if (got[c] != (float)want) bad++;
+            }
         }
         const long long na = 4096, ny = 2 * 1665 + 1;
         for (long long i = (long long)tid; i < na * ny * 8; i += (long long)nthreads) {
