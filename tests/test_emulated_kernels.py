@@ -425,3 +425,49 @@ def test_emu_poly_add_sub_and_vector_multiply(emu, oracle, golden_npz):
             assert emu.emu_vecmul(k, C.c_size_t(5), p16(u), p16(v), p16(w)) == 0
             assert (w == _vecmul_expect(oracle, u, v)).all(), (k, hi)
     assert emu.emu_vecmul(5, C.c_size_t(1), p16(a), p16(b), p16(out)) == -1
+
+
+@pytest.mark.parametrize("pset", (512, 768, 1024))
+def test_emu_two_items_per_wave_every_batch_parity_and_piece_compare(emu, oracle, pset):
+    """mlkem_kpke2.hpp: two items per wave, so odd batches leave the upper half-wave without an item (it recomputes the last
+    item and must store nothing), and the re-encryption compare works on register pieces whose dwords neighbouring lanes share
+    (d = 10: lane pairs, d = 11 / 5: quads).  For n = 1, 2, 3 (+ guard rows behind every output): K-PKE.KeyGen / Encrypt bytes
+    against the oracle; then one flipped bit in a byte of EVERY dword class of the ciphertext — first / shared / last dword of
+    a lane group in every polynomial row and in v — must turn K into the implicit-rejection key."""
+    ekl, dkl, cl = SIZES[pset]
+    k = {512: 2, 768: 3, 1024: 4}[pset]
+    du, dv = (10, 4) if k < 4 else (11, 5)
+    for n in (1, 2, 3):
+        d, z, m = seeds("k2-d", n, pset), seeds("k2-z", n, pset), seeds("k2-m", n, pset)
+        ek, dk = np.full((n + 1, ekl), 0xA5, np.uint8), np.full((n + 1, dkl), 0xA5, np.uint8)
+        assert emu.emu_keygen(pset, C.c_size_t(n), p8(d), p8(z), p8(ek), p8(dk)) == 0
+        ek_o, dk_o = oracle.keygen(pset, d, z)
+        assert (ek[:n] == ek_o).all() and (dk[:n] == dk_o).all() and (ek[n] == 0xA5).all() and (dk[n] == 0xA5).all(), n
+        c, K = np.full((n + 1, cl), 0x5A, np.uint8), np.full((n + 1, 32), 0x5A, np.uint8)
+        assert emu.emu_encaps(pset, C.c_size_t(n), p8(ek), p8(m), p8(c), p8(K), None) == 0
+        c_o, K_o = oracle.encaps(pset, ek_o, m)
+        assert (c[:n] == c_o).all() and (K[:n] == K_o).all() and (c[n] == 0x5A).all() and (K[n] == 0x5A).all(), n
+    # byte positions: for every polynomial row, the first / second / last bytes of the first and last lane groups and one in
+    # the middle; for v likewise
+    pos = []
+    for row in range(k):
+        base = row * 32 * du
+        pos += [base, base + 4, base + 9, base + 10, base + 11, base + 19, base + 20, base + 16 * du + 3, base + 32 * du - 12, base + 32 * du - 1]
+    vb = k * 32 * du
+    pos += [vb, vb + 2, vb + 4, vb + 5, vb + 19, vb + 16 * dv, vb + 32 * dv - 6, vb + 32 * dv - 1]
+    n = len(pos)
+    d, z, m = seeds("k2p-d", 1, pset), seeds("k2p-z", 1, pset), seeds("k2p-m", n, pset)
+    ek1, dk1 = oracle.keygen(pset, d, z)
+    ekr, dkr = np.repeat(ek1, n, 0), np.repeat(dk1, n, 0)
+    c, K = oracle.encaps(pset, ekr, m)
+    cb = c.copy()
+    for i, p in enumerate(pos):
+        cb[i, p] ^= 1 << (i % 8)
+    Kd, st = np.zeros((n, 32), np.uint8), np.zeros(n, np.int32)
+    assert emu.emu_decaps(pset, C.c_size_t(n), p8(dkr), p8(cb), p8(Kd), st.ctypes.data_as(C.POINTER(C.c_int32)), 1) == 0
+    Ko, sto = oracle.decaps(pset, dkr, cb)
+    assert (st == 0).all() and (sto == 0).all() and (Kd == Ko).all()
+    assert not (Kd == K).all(axis=1).any()            # every one of them rejected
+    Kd2 = np.zeros((n, 32), np.uint8)
+    assert emu.emu_decaps(pset, C.c_size_t(n), p8(dkr), p8(c), p8(Kd2), st.ctypes.data_as(C.POINTER(C.c_int32)), 1) == 0
+    assert (Kd2 == K).all()                            # and the untouched ciphertexts accepted

@@ -306,3 +306,30 @@ def test_bench_default_line_has_three_cpu_legs(tmp_path):
         assert legs["reference_O0"]["per_core"] < legs["reference_O2"]["per_core"] < legs["port"]["per_core"]
     rf = j["roofline"]
     assert rf["dominant_kernel"] and rf["whole_pass"]["frac"] <= rf["frac"] < 1 and len(j["per_gpu"]) == 1
+
+
+# ---- the re-encryption compare looks at every byte ------------------------------------------------------------------------
+@pytest.mark.parametrize("pset", (512, 768, 1024))
+def test_every_ciphertext_byte_takes_part_in_the_compare(pkg, torch, oracle, pset):
+    """mlkem_kpke2.hpp compares the re-encrypted ciphertext as register pieces (dwords that two or four lanes share are owned by
+    one of them).  Item i of the batch carries a ciphertext with one bit flipped in byte i, for EVERY byte of c: all of them must
+    come back with the implicit-rejection key (oracle on a spread subset), the untouched batch with K."""
+    ekl, dkl, cl = SIZES[pset]
+    e = pkg.MLKEM(pset, device=0, chunk_items=512)
+    n = cl
+    d, z, m = seeds("cmp-d", n, pset), seeds("cmp-z", n, pset), seeds("cmp-m", n, pset)
+    ek, dk = e.keygen(dev(torch, d), dev(torch, z))
+    c, K = e.encaps(ek, dev(torch, m))
+    ch = host(c)
+    cb = ch.copy()
+    cb[np.arange(n), np.arange(n)] ^= (1 << (np.arange(n) % 8)).astype(np.uint8)
+    Kd, st = e.decaps(dk, dev(torch, cb))
+    K0, st0 = e.decaps(dk, c)
+    torch.cuda.synchronize()
+    Kh, Kdh = host(K), host(Kd)
+    assert (host(st) == 0).all() and (host(st0) == 0).all() and (host(K0) == Kh).all()
+    assert not (Kdh == Kh).all(axis=1).any(), np.nonzero((Kdh == Kh).all(axis=1))[0][:10]
+    sub = np.arange(0, n, 53)
+    Ko, sto = oracle.decaps(pset, host(dk)[sub], cb[sub])
+    assert (Kdh[sub] == Ko).all() and (sto == 0).all()
+    e.close()
