@@ -667,7 +667,7 @@ __device__ __forceinline__ void k2_canon(const v2f (&p)[4], unsigned (&c)[8]) {
 // Arguments as k_keygen (mlkem_arith.hpp).
 // ------------------------------------------------------------------------------------------------
 template <int K, int ETA1, bool KEM_DK>
-__global__ void __launch_bounds__(WAVE * KPKE2_WAVES, kpke2_minwaves(K + 1))   // s-hat AND e-hat stay in registers: the budget of the next k
+__global__ void __launch_bounds__(WAVE * KPKE2_WAVES, K == 2 ? kpke2_minwaves(2) : kpke2_minwaves(K + 1))   // s-hat AND e-hat stay in registers
 k_keygen2(size_t n, const uint16_t* __restrict__ A, const uint8_t* __restrict__ prf, const uint8_t* __restrict__ rho,
           uint8_t* __restrict__ ek, uint8_t* __restrict__ dk) {
     __shared__ K2Lds<K> lds_all[KPKE2_WAVES];
@@ -687,11 +687,14 @@ k_keygen2(size_t n, const uint16_t* __restrict__ A, const uint8_t* __restrict__ 
     K2CbdRaw<ETA1> raw_s[K], raw_e[K];
 #pragma unroll
     for (int b = 0; b < K; b++) k2_cbd_load_la<ETA1>(my_prf + b * PS, t, raw_s[b]);
+    constexpr bool PF = K >= 3;                        // k = 2 keeps four waves per SIMD instead (measured: prefetch there costs 5 %)
     uint4 a_all[K][K];                                 // the whole matrix, requested up front (see k_encrypt2)
+    if constexpr (PF) {
 #pragma unroll
-    for (int a = 0; a < K; a++)
+        for (int a = 0; a < K; a++)
 #pragma unroll
-        for (int b = 0; b < K; b++) a_all[a][b] = *reinterpret_cast<const uint4*>(my_A + (a * K + b) * 256 + 8 * nb);
+            for (int b = 0; b < K; b++) a_all[a][b] = *reinterpret_cast<const uint4*>(my_A + (a * K + b) * 256 + 8 * nb);
+    }
 #pragma unroll
     for (int a = 0; a < K; a++) k2_cbd_load_la<ETA1>(my_prf + (K + a) * PS, t, raw_e[a]);
     const uint32_t rho_w = reinterpret_cast<const uint32_t*>(rho + item * 32)[t & 7];
@@ -725,6 +728,7 @@ k_keygen2(size_t n, const uint16_t* __restrict__ A, const uint8_t* __restrict__ 
 #pragma unroll
         for (int b = 0; b < K; b++) {
             v2f av[4];
+            if constexpr (!PF) a_all[a][b] = *reinterpret_cast<const uint4*>(my_A + (a * K + b) * 256 + 8 * nb);
             k2_unpack16(a_all[a][b], av);
             k2_basemul_acc(acc, av, sh[b], sg[b]);
         }
