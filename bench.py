@@ -578,11 +578,13 @@ def entry(workload, args, elapsed, ok, extra, world):
     if tpath:
         t = json.load(open(tpath))
         if t.get("source_id") == source_id() and t.get("batch") == args.batch:
-            roofline["traffic"] = t["hbm_bytes_per_step_corrected"]
-            roofline["traffic_note"] = "bytes per STEP (all kernels) from %s (git %s, source_id %s): (2*FETCH_SIZE + WRITE_SIZE)*1024; raw = %.3g" % (
-                os.path.relpath(tpath, ROOT), t.get("git_head", "?"), t["source_id"], t["hbm_bytes_per_step_raw"])
-            if dom and t.get("per_label", {}).get(dom):
-                roofline["dominant_kernel_traffic_per_launch"] = t["per_label"][dom]["bytes_per_launch_corrected"]
+            # `traffic` is per LAUNCH of the dominant kernel, like `achieved`; the all-kernel figure of one step stands beside it
+            pl = t.get("per_label", {}).get(dom) if dom else None
+            roofline["traffic"] = pl["bytes_per_launch_corrected"] if pl else None
+            roofline["traffic_per_step"] = t["hbm_bytes_per_step_corrected"]
+            roofline["traffic_note"] = ("traffic = HBM bytes per launch of %s, traffic_per_step = all kernels of one step; from %s (git %s, "
+                                        "source_id %s): (2*FETCH_SIZE + WRITE_SIZE)*1024 as MI355X_MICROARCH.md prescribes; raw per step = %.3g" % (
+                                            dom, os.path.relpath(tpath, ROOT), t.get("git_head", "?"), t["source_id"], t["hbm_bytes_per_step_raw"]))
         else:
             roofline["traffic_note"] = "%s was measured on another build (source_id %s != %s) or batch: not attached" % (
                 os.path.relpath(tpath, ROOT), t.get("source_id"), source_id())
