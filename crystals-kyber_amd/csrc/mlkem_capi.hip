@@ -150,6 +150,21 @@ int mlkem_ctx_create(mlkem_ctx** out, int device, size_t chunk_items) {
     c->ws.Kbar = c->ws.Kp + sz32;
     c->ws.cap = n;
     c->ws.hcap = hn;
+    // side stream + fork / join events for calls of one chunk (SideFork, mlkem_pipeline.hpp); MLKEM_SIDE_STREAM=0 keeps every
+    // call on the caller's stream.  Failing to create them is not an error: the context then works without the overlap.
+    const char* se = getenv("MLKEM_SIDE_STREAM");
+    if (!(se && atoi(se) == 0)) {
+        if (hipStreamCreateWithFlags(&c->ws.side, hipStreamNonBlocking) != hipSuccess) c->ws.side = nullptr;
+        if (c->ws.side && (hipEventCreateWithFlags(&c->ws.ev_fork, hipEventDisableTiming) != hipSuccess ||
+                           hipEventCreateWithFlags(&c->ws.ev_join, hipEventDisableTiming) != hipSuccess)) {
+            if (c->ws.ev_fork) (void)hipEventDestroy(c->ws.ev_fork);
+            if (c->ws.ev_join) (void)hipEventDestroy(c->ws.ev_join);
+            (void)hipStreamDestroy(c->ws.side);
+            c->ws.side = nullptr;
+            c->ws.ev_fork = c->ws.ev_join = nullptr;
+            (void)hipGetLastError();
+        }
+    }
     *out = c;
     return MLKEM_OK;
 }
@@ -159,6 +174,12 @@ void mlkem_ctx_destroy(mlkem_ctx* ctx) {
     int prev = -1;
     (void)hipGetDevice(&prev);
     (void)hipSetDevice(ctx->device);
+    if (ctx->ws.side) {
+        (void)hipStreamSynchronize(ctx->ws.side);
+        (void)hipEventDestroy(ctx->ws.ev_fork);
+        (void)hipEventDestroy(ctx->ws.ev_join);
+        (void)hipStreamDestroy(ctx->ws.side);
+    }
     if (ctx->scratch) {
         (void)hipMemset(ctx->scratch, 0, ctx->scratch_bytes);   // r, m', K', K-bar, PRF output: secret-dependent intermediates
         (void)hipFree(ctx->scratch);

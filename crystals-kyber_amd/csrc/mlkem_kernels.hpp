@@ -381,6 +381,10 @@ __global__ void __launch_bounds__(256) k_status_fill(size_t n, const uint8_t* __
 // k_hash_decaps — KEM_Decaps hash check (ml_kem.c:1336-1350) and Decaps_internal's hashing
 // (ml_kem.c:1187-1202): status = (H(dk.ek) == dk.h) ? 0 : -5 ; (K', r') = G(m' || dk.h) ; Kbar = J(dk.z || c)
 // J is SHAKE128 in the reference (F2): JRATE = 168; the FIPS 203 mode uses SHAKE256: JRATE = 136.
+// The three sponges of an item are independent.  With HASH_CHECK the grid holds TWO waves per 64 items: blocks [0, nb) run
+// H(ek) (9 permutations for k = 3), blocks [nb, 2 nb) run J and G (7 + 1) -- the same permutations in all, but a chain of 9
+// instead of 17 per lane: below ~2^16 items the GPU is not full and the kernel's time is the length of that chain
+// (0.174 -> 0.10 ms at 64..16384 items), at 2^20 it is neutral (profiles/r03_batch_sweep.txt).
 // ------------------------------------------------------------------------------------------------
 template <int K, int CLEN, bool HASH_CHECK, int JRATE = 168>
 __global__ void __launch_bounds__(WAVE, MLKEM_KECCAK_MINWAVES) k_hash_decaps(size_t n, const uint8_t* __restrict__ dk, const uint8_t* __restrict__ c,
@@ -391,20 +395,22 @@ __global__ void __launch_bounds__(WAVE, MLKEM_KECCAK_MINWAVES) k_hash_decaps(siz
     __shared__ __attribute__((aligned(16))) uint2 stage[STAGE_QWORDS];
     constexpr unsigned EK = 384 * K + 32;
     const size_t DK = dk_stride;
-    const size_t item0 = (size_t)blockIdx.x * WAVE, item = item0 + lane_id();
+    const size_t nb = (n + WAVE - 1) / WAVE;
+    const bool check_role = HASH_CHECK && blockIdx.x < nb;
+    const size_t item0 = (size_t)(HASH_CHECK && !check_role ? blockIdx.x - nb : blockIdx.x) * WAVE, item = item0 + lane_id();
     const size_t it = item < n ? item : n - 1;
     KeccakState s;
     uint32_t h[8], w[8];
     load32(dk + 768 * K + 32, DK, it, h);
-    int st = 0;
-    if constexpr (HASH_CHECK) {
+    if (check_role) {
         MsgView mv{dk + 384 * K, DK, EK, dk, DK, 0};
         wave_sponge_absorb<136, 0x06>(s, stage, mv, item0, n);
         MLKEM_STATE_WORDS8(s, 0, w)
         uint32_t diff = 0;
 #pragma unroll
         for (int i = 0; i < 8; i++) diff |= w[i] ^ h[i];
-        st = diff ? -5 : 0;
+        if (item < n && status) status[item] = diff ? -5 : 0;
+        return;
     }
     // Kbar = J(z || c)
     {
@@ -424,7 +430,7 @@ __global__ void __launch_bounds__(WAVE, MLKEM_KECCAK_MINWAVES) k_hash_decaps(siz
         store32(Kp_ws, 32, item, w);
         MLKEM_STATE_WORDS8(s, 8, w)
         store32(r_ws, 32, item, w);
-        if (status) status[item] = st;
+        if (!HASH_CHECK && status) status[item] = 0;
     }
 }
 

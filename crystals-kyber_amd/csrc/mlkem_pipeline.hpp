@@ -112,11 +112,49 @@ struct Workspace {
     size_t hcap = 0;   // h-chunk capacity (items) of the 32-byte arrays
     int fips = 0;      // 0: bit-identical to the reference (PRF, J on SHAKE128; no-op modulus check)
                        // 1: FIPS 203 conformant (PRF, J on SHAKE256; encaps reports status -4 for t-hat coefficients >= q)
+#ifndef MLKEM_EMU
+    // side stream of the context + fork / join events: calls that fit ONE chunk sample the matrix there while the hash
+    // kernels run on the caller's stream (SideFork below); null = everything on the caller's stream
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+#endif
 };
-// Everything of one call runs on the caller's stream, chunk after chunk: sampler -> leftover passes -> arithmetic.  A
-// two-stream pipeline (arithmetic of chunk i beside the sampler of chunk i + 1, also with the arithmetic confined to a subset
-// of the CUs) and a phase-separated schedule were measured and do not pay: the pass is energy-limited
-// (profiles/r02_sampler_experiments.txt, profiles/r03_power_schedule.txt).
+// A call of more than one chunk runs on the caller's stream alone, chunk after chunk: sampler -> leftover passes ->
+// arithmetic.  A two-stream pipeline over chunks (arithmetic of chunk i beside the sampler of chunk i + 1, also with the
+// arithmetic confined to a subset of the CUs) and a phase-separated schedule were measured and do not pay at 2^20 items: the
+// pass is energy-limited (profiles/r02_sampler_experiments.txt, profiles/r03_power_schedule.txt).
+// A call that fits one chunk does not fill the GPU for long (one sponge per lane: 2^14 items are 256 waves of hashing on 1024
+// SIMDs) and its time is the LENGTH of its dependency chain: H(ek) -> G -> PRF -> Encrypt on one side, SampleNTT (which needs
+// only rho) on the other.  SideFork runs the matrix sampling on the context's side stream from the start of the call and
+// joins before the arithmetic kernel (profiles/r03_batch_sweep.txt).
+struct SideFork {
+    stream_t main, side = nullptr;
+#ifndef MLKEM_EMU
+    hipEvent_t join = nullptr;
+#endif
+    // active only when the whole call is one chunk: the side stream then owns ws.A / ws.leftover / ws.resume until join()
+    SideFork(const Workspace& ws, stream_t st, size_t n) : main(st) {
+#ifndef MLKEM_EMU
+        if (ws.side && n <= ws.cap && hipEventRecord(ws.ev_fork, st) == hipSuccess && hipStreamWaitEvent(ws.side, ws.ev_fork, 0) == hipSuccess) {
+            side = ws.side;
+            join = ws.ev_join;
+        }
+#else
+        (void)ws; (void)n;
+#endif
+    }
+    bool active() const { return side != nullptr; }
+    stream_t xof_stream() const { return side ? side : main; }
+    void join_main() {   // everything launched on the side stream so far precedes what follows on the caller's stream
+#ifndef MLKEM_EMU
+        if (side) {
+            // a failed record / wait leaves no ordering: fall back to a full wait for the side stream
+            if (hipEventRecord(join, side) != hipSuccess || hipStreamWaitEvent(main, join, 0) != hipSuccess) (void)hipStreamSynchronize(side);
+            side = nullptr;
+        }
+#endif
+    }
+};
 
 inline size_t ceil_div(size_t a, size_t b) { return (a + b - 1) / b; }
 inline size_t min_sz(size_t a, size_t b) { return a < b ? a : b; }
@@ -139,7 +177,7 @@ inline void launch_sample_split(stream_t st, const ParamSet& p, size_t n_xof_ite
     a.resume_cap = ws.resume ? ws.resume_cap : 0;
     a.list_mode = 0;
     a.prf_rate = ws.fips ? 136 : 168;
-    zero_u32x2(st, ws.leftover);
+    if (a.n_xof) zero_u32x2(st, ws.leftover);   // the counters belong to the stream that samples the matrix
     const size_t grid = a.xof_blocks + ceil_div(a.n_prf, WAVE);
     if (grid == 0) return;
     launch("k_sample_main", k_sample_main, grid, WAVE, st, a);
@@ -198,6 +236,8 @@ template <int K, int ETA1, int DU, int DV>
 // r_user != nullptr: K-PKE.Encrypt alone (ml_kem.c:776-936) with the caller's randomness; no hashing, Kout unused
 inline void encaps_run(stream_t st, const ParamSet& p, size_t n, const uint8_t* ek, const uint8_t* m, uint8_t* c, uint8_t* Kout,
                        int32_t* mod_status, const Workspace& ws, const uint8_t* r_user = nullptr) {
+    SideFork fork(ws, st, r_user ? (size_t)-1 : n);   // one chunk: A-hat^T (needs rho alone) is sampled beside H(ek) and G
+    if (fork.active()) launch_sample_split(fork.xof_stream(), p, n, 0, ek + 384 * K, p.ek_len, /*transpose=*/1, nullptr, 2 * K + 1, K, ws);
     for (size_t h0 = 0; h0 < n; h0 += ws.hcap) {
         const size_t hn = min_sz(ws.hcap, n - h0);
         const uint8_t* r_h = r_user ? r_user + h0 * 32 : (const uint8_t*)ws.r;
@@ -206,7 +246,12 @@ inline void encaps_run(stream_t st, const ParamSet& p, size_t n, const uint8_t* 
         for (size_t c0 = 0; c0 < hn; c0 += ws.cap) {
             const size_t cn = min_sz(ws.cap, hn - c0), i0 = h0 + c0;
             const uint8_t* eki = ek + i0 * p.ek_len;
-            launch_sample(st, p, cn, eki + 384 * K, p.ek_len, /*transpose=*/1, r_h + c0 * 32, 2 * K + 1, K, ws);
+            if (fork.active()) {   // PRF rows on the caller's stream (they need r), then wait for the matrix
+                launch_sample_split(st, p, 0, cn, nullptr, 0, 1, r_h + c0 * 32, 2 * K + 1, K, ws);
+                fork.join_main();
+            } else {
+                launch_sample(st, p, cn, eki + 384 * K, p.ek_len, /*transpose=*/1, r_h + c0 * 32, 2 * K + 1, K, ws);
+            }
             encrypt_launch<K, ETA1, DU, DV, false>("k_encrypt", st, cn, eki, (size_t)p.ek_len, m + i0 * 32, (const uint16_t*)ws.A, (const uint8_t*)ws.prf,
                    c + i0 * p.c_len, (const uint8_t*)nullptr, (const uint8_t*)nullptr, (const uint8_t*)nullptr, (uint8_t*)nullptr,
                    mod_status ? mod_status + i0 : (int32_t*)nullptr, (size_t)(K * K * 256));
@@ -231,21 +276,28 @@ inline void decaps_run(stream_t st, const ParamSet& p, size_t n, const uint8_t* 
         const size_t hn = min_sz(ws.hcap, n - h0);
         const uint8_t* dkh = dk + h0 * p.dk_len;
         const uint8_t* ch = c + h0 * p.c_len;
+        SideFork fork(ws, st, n);   // one chunk: A-hat^T of the re-encryption is sampled beside Decrypt and the three sponges
+        if (fork.active()) launch_sample_split(fork.xof_stream(), p, n, 0, dk + 768 * K, p.dk_len, /*transpose=*/1, nullptr, 2 * K + 1, K, ws);
         decrypt_launch<K, DU, DV>(st, hn, dkh, (size_t)p.dk_len, ch, ws.m);
         int32_t* sth = (hash_check && status) ? status + h0 : (int32_t*)nullptr;
         const size_t hgrid = ceil_div(hn, WAVE);
         if (hash_check && !ws.fips)
-            launch("k_hash_decaps", k_hash_decaps<K, CLEN, true, 168>, hgrid, WAVE, st, hn, dkh, ch, (const uint8_t*)ws.m, ws.Kp, ws.r, ws.Kbar, sth, (size_t)p.dk_len);
+            launch("k_hash_decaps", k_hash_decaps<K, CLEN, true, 168>, 2 * hgrid, WAVE, st, hn, dkh, ch, (const uint8_t*)ws.m, ws.Kp, ws.r, ws.Kbar, sth, (size_t)p.dk_len);
         else if (!ws.fips)
             launch("k_hash_decaps", k_hash_decaps<K, CLEN, false, 168>, hgrid, WAVE, st, hn, dkh, ch, (const uint8_t*)ws.m, ws.Kp, ws.r, ws.Kbar, sth, (size_t)p.dk_len);
         else if (hash_check)
-            launch("k_hash_decaps", k_hash_decaps<K, CLEN, true, 136>, hgrid, WAVE, st, hn, dkh, ch, (const uint8_t*)ws.m, ws.Kp, ws.r, ws.Kbar, sth, (size_t)p.dk_len);
+            launch("k_hash_decaps", k_hash_decaps<K, CLEN, true, 136>, 2 * hgrid, WAVE, st, hn, dkh, ch, (const uint8_t*)ws.m, ws.Kp, ws.r, ws.Kbar, sth, (size_t)p.dk_len);
         else
             launch("k_hash_decaps", k_hash_decaps<K, CLEN, false, 136>, hgrid, WAVE, st, hn, dkh, ch, (const uint8_t*)ws.m, ws.Kp, ws.r, ws.Kbar, sth, (size_t)p.dk_len);
         for (size_t c0 = 0; c0 < hn; c0 += ws.cap) {
             const size_t cn = min_sz(ws.cap, hn - c0), i0 = h0 + c0;
             const uint8_t* dki = dk + i0 * p.dk_len;
-            launch_sample(st, p, cn, dki + 768 * K, p.dk_len, /*transpose=*/1, ws.r + c0 * 32, 2 * K + 1, K, ws);
+            if (fork.active()) {
+                launch_sample_split(st, p, 0, cn, nullptr, 0, 1, ws.r + c0 * 32, 2 * K + 1, K, ws);
+                fork.join_main();
+            } else {
+                launch_sample(st, p, cn, dki + 768 * K, p.dk_len, /*transpose=*/1, ws.r + c0 * 32, 2 * K + 1, K, ws);
+            }
             encrypt_launch<K, ETA1, DU, DV, true>("k_encrypt_cmp", st, cn, dki + 384 * K, (size_t)p.dk_len, (const uint8_t*)(ws.m + c0 * 32), (const uint16_t*)ws.A,
                    (const uint8_t*)ws.prf, (uint8_t*)nullptr, c + i0 * p.c_len, (const uint8_t*)(ws.Kp + c0 * 32),
                    (const uint8_t*)(ws.Kbar + c0 * 32), Kout + i0 * 32, (int32_t*)nullptr, (size_t)(K * K * 256));

@@ -333,3 +333,34 @@ def test_every_ciphertext_byte_takes_part_in_the_compare(pkg, torch, oracle, pse
     Ko, sto = oracle.decaps(pset, host(dk)[sub], cb[sub])
     assert (Kdh[sub] == Ko).all() and (sto == 0).all()
     e.close()
+
+
+# ---- calls of one chunk: matrix sampling on the context's side stream ------------------------------------------------------
+@pytest.mark.parametrize("env", ({}, {"MLKEM_SIDE_STREAM": "0"}), ids=("side-stream", "one-stream"))
+@pytest.mark.parametrize("pset,n", ((768, 1000), (512, 3), (1024, 130)))
+def test_single_chunk_calls_keep_their_results_with_and_without_the_side_stream(pkg, torch, oracle, env, monkeypatch, pset, n):
+    """A call that fits one chunk samples A-hat on the context's side stream while H(ek) / G (encaps) or Decrypt and the
+    three sponges (decaps) run on the caller's stream (SideFork, mlkem_pipeline.hpp).  Six rounds of keygen -> encaps ->
+    decaps with different data are queued back to back WITHOUT a synchronisation in between: a matrix sampled too early
+    (before the previous call's arithmetic has read the scratch) or joined too late would change bytes.  Same bytes with the
+    side stream disabled."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    e = pkg.MLKEM(pset, device=0, chunk_items=1024)
+    outs = []
+    for rnd in range(6):
+        d, z, m = seeds("sf-d%d" % rnd, n, pset), seeds("sf-z%d" % rnd, n, pset), seeds("sf-m%d" % rnd, n, pset)
+        ek, dk = e.keygen(dev(torch, d), dev(torch, z))
+        c, K = e.encaps(ek, dev(torch, m))
+        cb = c.clone()
+        cb[::7, rnd] ^= 0x20                                  # every 7th ciphertext tampered: implicit rejection
+        Kd, st = e.decaps(dk, cb)
+        outs.append((d, z, m, ek, dk, c, K, cb, Kd, st))
+    torch.cuda.synchronize()
+    for d, z, m, ek, dk, c, K, cb, Kd, st in outs:
+        ek_o, dk_o = oracle.keygen(pset, d, z)
+        c_o, K_o = oracle.encaps(pset, ek_o, m)
+        Kd_o, st_o = oracle.decaps(pset, dk_o, host(cb))
+        assert (host(ek) == ek_o).all() and (host(dk) == dk_o).all() and (host(c) == c_o).all() and (host(K) == K_o).all()
+        assert (host(Kd) == Kd_o).all() and (host(st) == st_o).all()
+    e.close()
