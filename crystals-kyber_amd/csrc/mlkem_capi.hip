@@ -685,12 +685,17 @@ int stream_op(StreamEngine& e, size_t n, size_t chunk, const std::vector<Span>& 
     bool any_staged = false;
     for (char c : staged) any_staged = any_staged || c;
     std::vector<void*> devp(spans.size());
+    // One chunk: nothing to overlap, so copy-in, kernels and copy-out go down the kernel stream in order and the call saves the
+    // two cross-stream event hops (host-pointer Encaps + Decaps of <= 64 items: 431 -> see profiles/r03_host_latency.txt).
+    // Every call ends with its streams drained, so the choice is per call.
+    const bool single = nchunks == 1;
+    const hipStream_t sh = single ? e.k : e.h2d, sd = single ? e.k : e.d2h;
     size_t i = 0;
     for (size_t off = 0; off < n && rc == MLKEM_OK; off += chunk, i++) {
         BufSet& s = e.set[i % nsets];
         const size_t cnt = n - off < chunk ? n - off : chunk;
         if (any_staged && (rc = drain(s)) != MLKEM_OK) break;        // frees the set's pinned buffers (and implies its H2D is done)
-        (void)hipStreamWaitEvent(e.h2d, s.evK, 0);                   // the set's previous kernels have consumed its inputs
+        if (!single) (void)hipStreamWaitEvent(sh, s.evK, 0);         // the set's previous kernels have consumed its inputs
         for (size_t j = 0; j < spans.size() && rc == MLKEM_OK; j++) {
             devp[j] = s.buf[j].dev;
             if (!spans[j].in) continue;
@@ -699,28 +704,32 @@ int stream_op(StreamEngine& e, size_t n, size_t chunk, const std::vector<Span>& 
                 par_memcpy(s.buf[j].pin, src, cnt * spans[j].bytes);
                 src = static_cast<const uint8_t*>(s.buf[j].pin);
             }
-            if (!hip_ok(hipMemcpyAsync(s.buf[j].dev, src, cnt * spans[j].bytes, hipMemcpyHostToDevice, e.h2d), "H2D")) rc = MLKEM_ERR_NO_DEVICE;
+            if (!hip_ok(hipMemcpyAsync(s.buf[j].dev, src, cnt * spans[j].bytes, hipMemcpyHostToDevice, sh), "H2D")) rc = MLKEM_ERR_NO_DEVICE;
         }
         if (rc != MLKEM_OK) break;
-        (void)hipEventRecord(s.evH, e.h2d);
-        (void)hipStreamWaitEvent(e.k, s.evH, 0);
-        (void)hipStreamWaitEvent(e.k, s.evD, 0);                     // the set's previous outputs have left the device
+        if (!single) {
+            (void)hipEventRecord(s.evH, sh);
+            (void)hipStreamWaitEvent(e.k, s.evH, 0);
+            (void)hipStreamWaitEvent(e.k, s.evD, 0);                 // the set's previous outputs have left the device
+        }
         rc = launch(e.ctx, cnt, devp, e.k);
         if (rc != MLKEM_OK) break;
-        (void)hipEventRecord(s.evK, e.k);
-        (void)hipStreamWaitEvent(e.d2h, s.evK, 0);
+        if (!single) {
+            (void)hipEventRecord(s.evK, e.k);
+            (void)hipStreamWaitEvent(sd, s.evK, 0);
+        }
         for (size_t j = 0; j < spans.size() && rc == MLKEM_OK; j++) {
             if (!spans[j].out) continue;
             void* dst = staged[j] ? s.buf[j].pin : static_cast<void*>(static_cast<uint8_t*>(spans[j].out) + off * spans[j].bytes);
-            if (!hip_ok(hipMemcpyAsync(dst, s.buf[j].dev, cnt * spans[j].bytes, hipMemcpyDeviceToHost, e.d2h), "D2H")) rc = MLKEM_ERR_NO_DEVICE;
+            if (!hip_ok(hipMemcpyAsync(dst, s.buf[j].dev, cnt * spans[j].bytes, hipMemcpyDeviceToHost, sd), "D2H")) rc = MLKEM_ERR_NO_DEVICE;
         }
-        (void)hipEventRecord(s.evD, e.d2h);
+        (void)hipEventRecord(s.evD, sd);
         s.pending = cnt;
         s.pending_off = off;
     }
     // hand over in issue order: the oldest pending set first
     for (int k = 0; k < nsets && rc == MLKEM_OK; k++) rc = drain(e.set[(i + k) % nsets]);
-    if (rc == MLKEM_OK && !hip_ok(hipStreamSynchronize(e.d2h), "hipStreamSynchronize")) rc = MLKEM_ERR_NO_DEVICE;
+    if (rc == MLKEM_OK && !hip_ok(hipStreamSynchronize(sd), "hipStreamSynchronize")) rc = MLKEM_ERR_NO_DEVICE;
     if (rc != MLKEM_OK) engine_release(e);   // leave nothing half-done behind
     return rc;
 }

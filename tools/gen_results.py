@@ -9,6 +9,7 @@ files under profiles/ (so that prose and profiles cannot drift apart):
   profiles/<tag>_pmc_sq_<wl>.txt         SQ counters (tools/pmc_summary.py)
   profiles/<tag>_rehearsal_gpus2.json, <tag>_inproc8.json   the N > 1 forms of the bench line on the one GPU
   profiles/<tag>_gpu_tier.log            `pytest -m gpu` on the GPU box (test count)
+  profiles/<tag>_batch_sweep_head.txt, <tag>_host_latency.txt, <tag>_stream_bench.json   batch-size sweep, host-pointer latency and streaming rate
 
 Writes profiles/<tag>_RESULTS.md and replaces the text between `<!-- BEGIN GENERATED <tag> -->` and `<!-- END GENERATED <tag> -->`
 in DESIGN.md and README.md with it."""
@@ -170,6 +171,30 @@ def main():
         L.append("|---|---|---|---|---|---|---|")
         for p in j["per_gpu"]:
             L.append("| %d | %d | %.3g | %.2f | %s | %s | %s |" % (p["rank"], p["device"], p["value"], p["ms_per_step"], p["sclk_mhz"], p["socket_w"], p["correct"]))
+        L.append("")
+    sweep = os.path.join(P, "%s_batch_sweep_head.txt" % TAG)
+    if os.path.exists(sweep):
+        L.append("**Batch size, device-resident ML-KEM-768 encaps + decaps** (`tools/batch_sweep.sh`, `profiles/%s_batch_sweep_head.txt`; the steps that led here: `profiles/%s_batch_sweep.txt`):\n" % (TAG, TAG))
+        L.append("| items per call | pairs/s | ms per encaps + decaps |")
+        L.append("|---|---|---|")
+        for ln in open(sweep):
+            m = re.match(r"n=2\^(\d+)\s+([\d.e+]+) pairs/s\s+([\d.]+) ms/step", ln)
+            if m:
+                L.append("| 2^%s | %s | %s |" % (m.group(1), m.group(2), m.group(3)))
+        L.append("")
+    hl = os.path.join(P, "%s_host_latency.txt" % TAG)
+    sb = load("stream_bench.json")
+    if os.path.exists(hl) or sb:
+        L.append("**Host-pointer entry points** (`mlkem_encaps` / `mlkem_decaps` on host buffers, PCIe inside the call):\n")
+        if os.path.exists(hl):
+            for ln in open(hl):
+                if ln.startswith("n="):
+                    L.append("* " + ln.strip() + " (`profiles/%s_host_latency.txt`)" % TAG)
+        if sb:
+            best = lambda kind: max((v, k) for k, v in sb.items() if k.startswith(kind + "_pairs_per_s_chunk_"))
+            for kind in ("pinned", "pageable"):
+                v, k = best(kind)
+                L.append("* streaming %d items, %s buffers: %.3g pairs/s at chunk %s (`profiles/%s_stream_bench.json`)" % (sb["items"], kind, v, k.rsplit("_", 1)[1], TAG))
         L.append("")
     log = os.path.join(P, "%s_gpu_tier.log" % TAG)
     if os.path.exists(log):

@@ -4,7 +4,8 @@
 #   per workload (kem768 / ntt / kem1024): kernel-trace + stats of bench.py, two PMC passes (FETCH_SIZE, WRITE_SIZE; separate
 #   runs, as MI355X_MICROARCH.md prescribes) whose CSVs tools/pmc_traffic.py turns into profiles/rNN_pmc_traffic_*.json, and
 #   an SQ pass (issue utilisation);
-#   the default bench line, the two-rank rehearsal (torch.distributed.run, per_gpu) and the in-process 8-member line.
+#   the default bench line, the two-rank rehearsal (torch.distributed.run, per_gpu) and the in-process 8-member line;
+#   the host-pointer call latency, the PCIe-inclusive streaming rate and the batch-size sweep.
 # Output: gpurun_out/prof_<tag>/.   The program after `--` is python3 itself (no env / bash -c hop under the profiler).
 set -u
 TAG=${1:-r03}
@@ -29,6 +30,10 @@ timeout -k 10 400 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2
     > "$OUT/rehearsal_gpus2.log" 2> "$OUT/rehearsal_gpus2.err" || { echo "FAILED rehearsal" >&2; exit 1; }
 grep -h '^{' "$OUT/rehearsal_gpus2.log" | tail -1 > "$OUT/rehearsal_gpus2.json"
 timeout -k 10 400 python3 bench.py --inproc --gpus 8 > "$OUT/inproc8.json" 2> "$OUT/inproc8.err" || { echo "FAILED inproc" >&2; exit 1; }
+# host-pointer path: call latency at 1 / 64 / 1024 items, PCIe-inclusive streaming rate, and the device-resident batch sweep
+timeout -k 10 200 python3 tools/host_latency.py 2>/dev/null > "$OUT/host_latency.txt" || { echo "FAILED host_latency" >&2; exit 1; }
+timeout -k 10 400 python3 tools/stream_bench.py 2>/dev/null | grep '^{' | tail -1 > "$OUT/stream_bench.json" || { echo "FAILED stream_bench" >&2; exit 1; }
+timeout -k 10 400 bash tools/batch_sweep.sh > "$OUT/batch_sweep.txt" 2>/dev/null || { echo "FAILED batch_sweep" >&2; exit 1; }
 cd /tmp
 for wl in kem768 ntt kem1024; do
     run kt_$wl --kernel-trace --stats --output-format csv -d "$OUT/kt_$wl" -o $wl -- python3 "$ROOT/bench.py" --workload $wl --no-cpu --no-also || exit 1

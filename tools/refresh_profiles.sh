@@ -20,6 +20,9 @@ cp $D/bench_kem512.json profiles/${T}_bench_kem512.json
 cp $D/bench_kem768_shared.json profiles/${T}_bench_shared.json
 cp $D/rehearsal_gpus2.json profiles/${T}_rehearsal_gpus2.json
 cp $D/inproc8.json profiles/${T}_inproc8.json
+cp $D/host_latency.txt profiles/${T}_host_latency.txt
+cp $D/stream_bench.json profiles/${T}_stream_bench.json
+cp $D/batch_sweep.txt profiles/${T}_batch_sweep_head.txt
 python - $T <<'P'
 import json, sys, bench
 t = sys.argv[1]
