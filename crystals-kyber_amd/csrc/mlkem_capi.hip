@@ -58,7 +58,25 @@ struct mlkem_ctx {
     size_t scratch_bytes = 0;
     void* scratch = nullptr;
     Workspace ws;
+    // side stream of one-chunk calls (SideFork, mlkem_pipeline.hpp).  Created on the first call that can use it, not with the
+    // context: an idle fourth stream in the process costs the streaming front-end 10 % of its pinned-buffer rate (the runtime
+    // multiplexes streams onto a few hardware queues; profiles/r03_batch_sweep.txt).  The front-end lends its idle copy stream
+    // to its own context instead (stream_op).
+    bool side_allowed = true;
+    hipStream_t own_side = nullptr;
 };
+
+// called by the *_dev entry points that fork: gives the context its side stream the first time a call fits one chunk
+static void ctx_arm_side(mlkem_ctx* ctx, size_t n) {
+    if (!ctx->side_allowed || !ctx->ws.side_on || ctx->ws.side || n == 0 || n > ctx->ws.cap) return;
+    if (hipStreamCreateWithFlags(&ctx->own_side, hipStreamNonBlocking) == hipSuccess) {
+        ctx->ws.side = ctx->own_side;
+    } else {
+        ctx->own_side = nullptr;
+        ctx->side_allowed = false;   // the context works without the overlap
+        (void)hipGetLastError();
+    }
+}
 
 // a context is bound to the device it was created on: its scratch lives there and `*_dev` calls launch on the CALLER's
 // current device, so a call made while another device is current is rejected instead of faulting on foreign memory
@@ -150,20 +168,17 @@ int mlkem_ctx_create(mlkem_ctx** out, int device, size_t chunk_items) {
     c->ws.Kbar = c->ws.Kp + sz32;
     c->ws.cap = n;
     c->ws.hcap = hn;
-    // side stream + fork / join events for calls of one chunk (SideFork, mlkem_pipeline.hpp); MLKEM_SIDE_STREAM=0 keeps every
-    // call on the caller's stream.  Failing to create them is not an error: the context then works without the overlap.
+    // fork / join events of one-chunk calls (SideFork, mlkem_pipeline.hpp); the side stream itself comes with the first such call
+    // (ctx_arm_side).  MLKEM_SIDE_STREAM=0 keeps every call on the caller's stream; failing to create the events does the same.
     const char* se = getenv("MLKEM_SIDE_STREAM");
-    if (!(se && atoi(se) == 0)) {
-        if (hipStreamCreateWithFlags(&c->ws.side, hipStreamNonBlocking) != hipSuccess) c->ws.side = nullptr;
-        if (c->ws.side && (hipEventCreateWithFlags(&c->ws.ev_fork, hipEventDisableTiming) != hipSuccess ||
-                           hipEventCreateWithFlags(&c->ws.ev_join, hipEventDisableTiming) != hipSuccess)) {
-            if (c->ws.ev_fork) (void)hipEventDestroy(c->ws.ev_fork);
-            if (c->ws.ev_join) (void)hipEventDestroy(c->ws.ev_join);
-            (void)hipStreamDestroy(c->ws.side);
-            c->ws.side = nullptr;
-            c->ws.ev_fork = c->ws.ev_join = nullptr;
-            (void)hipGetLastError();
-        }
+    c->side_allowed = !(se && atoi(se) == 0);
+    if (c->side_allowed && (hipEventCreateWithFlags(&c->ws.ev_fork, hipEventDisableTiming) != hipSuccess ||
+                            hipEventCreateWithFlags(&c->ws.ev_join, hipEventDisableTiming) != hipSuccess)) {
+        if (c->ws.ev_fork) (void)hipEventDestroy(c->ws.ev_fork);
+        if (c->ws.ev_join) (void)hipEventDestroy(c->ws.ev_join);
+        c->ws.ev_fork = c->ws.ev_join = nullptr;
+        c->side_allowed = false;
+        (void)hipGetLastError();
     }
     *out = c;
     return MLKEM_OK;
@@ -174,12 +189,12 @@ void mlkem_ctx_destroy(mlkem_ctx* ctx) {
     int prev = -1;
     (void)hipGetDevice(&prev);
     (void)hipSetDevice(ctx->device);
-    if (ctx->ws.side) {
-        (void)hipStreamSynchronize(ctx->ws.side);
-        (void)hipEventDestroy(ctx->ws.ev_fork);
-        (void)hipEventDestroy(ctx->ws.ev_join);
-        (void)hipStreamDestroy(ctx->ws.side);
+    if (ctx->own_side) {
+        (void)hipStreamSynchronize(ctx->own_side);
+        (void)hipStreamDestroy(ctx->own_side);
     }
+    if (ctx->ws.ev_fork) (void)hipEventDestroy(ctx->ws.ev_fork);
+    if (ctx->ws.ev_join) (void)hipEventDestroy(ctx->ws.ev_join);
     if (ctx->scratch) {
         (void)hipMemset(ctx->scratch, 0, ctx->scratch_bytes);   // r, m', K', K-bar, PRF output: secret-dependent intermediates
         (void)hipFree(ctx->scratch);
@@ -303,6 +318,7 @@ int mlkem_encaps_status_dev(mlkem_ctx* ctx, int set, size_t n, const uint8_t* ek
         HIP_TRY(hipMemsetAsync(status, 0, n * sizeof(int32_t), st));
         status = nullptr;
     }
+    ctx_arm_side(ctx, n);
     encaps_dispatch(st, set, n, ek, m, c, K, status, ctx->ws);
     HIP_TRY(hipGetLastError());
     return MLKEM_OK;
@@ -323,6 +339,7 @@ int mlkem_decaps_dev(mlkem_ctx* ctx, int set, size_t n, const uint8_t* dk, const
     if (!ctx_ok(ctx) || (n && (!dk || !c || !K))) return MLKEM_ERR_ARG;
     if (!aligned16(dk) || !aligned16(c) || !aligned16(K) || (reinterpret_cast<uintptr_t>(status) & 3u)) return MLKEM_ERR_ARG;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    ctx_arm_side(ctx, n);
     decaps_dispatch(st, set, n, dk, c, K, status, status != nullptr, ctx->ws);
     HIP_TRY(hipGetLastError());
     return MLKEM_OK;
@@ -690,6 +707,11 @@ int stream_op(StreamEngine& e, size_t n, size_t chunk, const std::vector<Span>& 
     // Every call ends with its streams drained, so the choice is per call.
     const bool single = nchunks == 1;
     const hipStream_t sh = single ? e.k : e.h2d, sd = single ? e.k : e.d2h;
+    if (rc == MLKEM_OK && e.ctx) {
+        // side-stream sampling only for a stand-alone chunk, and then on the front-end's own idle copy stream
+        e.ctx->ws.side_on = single && e.ctx->side_allowed;
+        if (e.ctx->ws.side_on) e.ctx->ws.side = e.h2d;
+    }
     size_t i = 0;
     for (size_t off = 0; off < n && rc == MLKEM_OK; off += chunk, i++) {
         BufSet& s = e.set[i % nsets];

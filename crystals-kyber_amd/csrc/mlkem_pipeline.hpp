@@ -117,6 +117,8 @@ struct Workspace {
     // kernels run on the caller's stream (SideFork below); null = everything on the caller's stream
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool side_on = true;   // the streaming front-end turns it off while several chunks are in flight: its copy streams already
+                           // keep the GPU busy, and a third compute stream cost 15 % of the pinned-buffer streaming rate
 #endif
 };
 // A call of more than one chunk runs on the caller's stream alone, chunk after chunk: sampler -> leftover passes ->
@@ -135,7 +137,7 @@ struct SideFork {
     // active only when the whole call is one chunk: the side stream then owns ws.A / ws.leftover / ws.resume until join()
     SideFork(const Workspace& ws, stream_t st, size_t n) : main(st) {
 #ifndef MLKEM_EMU
-        if (ws.side && n <= ws.cap && hipEventRecord(ws.ev_fork, st) == hipSuccess && hipStreamWaitEvent(ws.side, ws.ev_fork, 0) == hipSuccess) {
+        if (ws.side && ws.side_on && n <= ws.cap && hipEventRecord(ws.ev_fork, st) == hipSuccess && hipStreamWaitEvent(ws.side, ws.ev_fork, 0) == hipSuccess) {
             side = ws.side;
             join = ws.ev_join;
         }

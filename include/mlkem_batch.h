@@ -58,9 +58,10 @@ typedef struct mlkem_ctx mlkem_ctx;
 /* `chunk_items` = items per sampler/arithmetic chunk (0 = default 2^18, env MLKEM_CHUNK_ITEMS); scratch is
  * ~10 KiB x chunk_items, allocated once here so that no *_dev call allocates.  A context is bound to `device`: *_dev
  * calls launch on the caller's current HIP device and return MLKEM_ERR_ARG when that is not the context's device.
- * The context also owns one side stream (env MLKEM_SIDE_STREAM=0: none): an encaps / decaps call of at most `chunk_items`
- * items samples its matrix there while the hash kernels run on the caller's stream; fork and join are events inside the call,
- * so the caller's stream is ordered after all of the call's work exactly as without it (stream capture sees a fork/join). */
+ * The context gets one side stream with its first encaps / decaps call of at most `chunk_items` items (env
+ * MLKEM_SIDE_STREAM=0: never): such a call samples its matrix there while the hash kernels run on the caller's stream; fork and
+ * join are events inside the call, so the caller's stream is ordered after all of the call's work exactly as without it
+ * (stream capture sees a fork/join).  Contexts that only ever see larger calls create no stream. */
 int mlkem_ctx_create(mlkem_ctx** out, int device, size_t chunk_items);
 void mlkem_ctx_destroy(mlkem_ctx* ctx);
 size_t mlkem_ctx_scratch_bytes(const mlkem_ctx* ctx);
