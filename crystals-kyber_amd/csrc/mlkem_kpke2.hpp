@@ -43,9 +43,6 @@ constexpr int KPKE2_WAVES = MLKEM_KPKE2_WAVES;
 #define MLKEM_KPKE2_GROUP 5   // output polynomials whose inverse transforms run interleaved (>= K + 1: all at once; groups of 2
                               // keep y-hat live across a transform and need MORE registers: 156 instead of 138 at k = 3)
 #endif
-#ifndef MLKEM_KPKE2_YG
-#define MLKEM_KPKE2_YG 1      // 1: keep y[2j+1] * gamma_j of every y-hat polynomial in registers (4 per polynomial); 0: recompute per use
-#endif
 #ifdef MLKEM_KPKE2_MINWAVES
 constexpr int kpke2_minwaves(int) { return MLKEM_KPKE2_MINWAVES; }
 #else
@@ -540,23 +537,17 @@ k_encrypt2(size_t n, const uint8_t* __restrict__ ek, size_t ek_stride, const uin
 
     // ---- y-hat = NTT(CBD_eta1(PRF(r, n)))  n = 0..K-1   (ml_kem.c:826-836): K transforms interleaved, result in registers ----
     v2f yh[K][4];
-#if MLKEM_KPKE2_YG
-    float yg[K][4];
-#endif
-    Tw twd0, twd1;                                     // gamma of the lane's pairs = +-(d0, d1) of the forward set
+    float yg[K][4];                                    // y[2j+1] * gamma_j of every y-hat polynomial stays in registers (4 per polynomial)
     {
         K2Tw tw;
         k2_twiddles_fwd(tw, t);
-        twd0 = tw.d0; twd1 = tw.d1;
 #pragma unroll
         for (int b = 0; b < K; b++) k2_cbd_eval<ETA1>(raw_y[b], yh[b]);
         k2_ntt<K>(yh, xch, h, t, tw);
 #pragma unroll
         for (int b = 0; b < K; b++) {
             k2_fred_n<4>(yh[b]);
-#if MLKEM_KPKE2_YG
             k2_gamma(yh[b], tw.d0, tw.d1, yg[b]);
-#endif
         }
     }
     // ---- the K + 1 output polynomials, G at a time (ml_kem.c:854-904):
@@ -585,13 +576,7 @@ k_encrypt2(size_t n, const uint8_t* __restrict__ ek, size_t ek_stride, const uin
 #pragma unroll
                     for (int j = 0; j < 4; j++) over = over || (av[j].x >= F_Q) || (av[j].y >= F_Q);
                 }
-#if MLKEM_KPKE2_YG
                 k2_basemul_acc(acc[g], av, yh[b], yg[b]);
-#else
-                float ygb[4];
-                k2_gamma(yh[b], twd0, twd1, ygb);
-                k2_basemul_acc(acc[g], av, yh[b], ygb);
-#endif
             }
         }
         if constexpr (COMPARE) {                       // reference ciphertext pieces: in flight during the inverse transforms
