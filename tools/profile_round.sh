@@ -21,6 +21,8 @@ run() {   # name, rocprof args..., -- bench args
 }
 # the bench lines come FIRST, on the box as the driver finds it (a GPU that has been under load for minutes clocks ~3 % lower)
 cd "$ROOT"
+rm -f "$OUT/source_id.txt"
+python3 -c "import bench; print(bench.source_id())" > "$OUT/source_id.txt"   # refresh_profiles.sh checks it against the tree it stamps
 echo "== bench lines" >&2
 timeout -k 10 400 python3 bench.py > "$OUT/bench_default.json" 2> "$OUT/bench_default.err" || { echo "FAILED default bench" >&2; exit 1; }
 for wl in kem512 kem768_shared; do

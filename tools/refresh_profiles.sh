@@ -9,6 +9,12 @@ T=${1:?tag}; D=gpurun_out/prof_$T
 if [ -n "$(git status --porcelain -- crystals-kyber_amd/csrc include bench.py)" ]; then
   echo "kernel sources / bench.py differ from HEAD: commit first, then profile and refresh" >&2; exit 1
 fi
+# the raw data must come from THIS build: profile_round.sh leaves the hash of the kernel sources it ran on
+want=$(python -c "import bench; print(bench.source_id())")
+have=$(cat $D/source_id.txt 2>/dev/null)
+if [ "$want" != "$have" ]; then
+  echo "gpurun_out/prof_$T was measured on source_id '$have', the tree is '$want': run tools/profile_round.sh $T on the GPU first" >&2; exit 1
+fi
 for wl in kem768 ntt kem1024; do
   cp $D/kt_$wl/${wl}_kernel_stats.csv profiles/${T}_${wl}_kernel_stats.csv || exit 1
   python tools/pmc_traffic.py --fetch $D/fetch_$wl/${wl}_counter_collection.csv --write $D/write_$wl/${wl}_counter_collection.csv \
