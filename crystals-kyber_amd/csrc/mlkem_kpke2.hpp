@@ -39,10 +39,6 @@ namespace mlkem {
 #define MLKEM_KPKE2_WAVES 1   // waves per workgroup: 1 measured best (profiles/r03_kpke_experiments.txt)
 #endif
 constexpr int KPKE2_WAVES = MLKEM_KPKE2_WAVES;
-#ifndef MLKEM_KPKE2_GROUP
-#define MLKEM_KPKE2_GROUP 5   // output polynomials whose inverse transforms run interleaved (>= K + 1: all at once; groups of 2
-                              // keep y-hat live across a transform and need MORE registers: 156 instead of 138 at k = 3)
-#endif
 #ifdef MLKEM_KPKE2_MINWAVES
 constexpr int kpke2_minwaves(int) { return MLKEM_KPKE2_MINWAVES; }
 #else
@@ -497,7 +493,7 @@ __global__ void __launch_bounds__(WAVE * KPKE2_WAVES, kpke2_minwaves(K))
 k_encrypt2(size_t n, const uint8_t* __restrict__ ek, size_t ek_stride, const uint8_t* __restrict__ msg, const uint16_t* __restrict__ A,
            const uint8_t* __restrict__ prf, uint8_t* __restrict__ c_out, const uint8_t* __restrict__ c_in, const uint8_t* __restrict__ Kp,
            const uint8_t* __restrict__ Kbar, uint8_t* __restrict__ Kout, int32_t* __restrict__ mod_status, size_t a_stride) {
-    __shared__ K2Lds<(MLKEM_KPKE2_GROUP < K + 1 ? (K > MLKEM_KPKE2_GROUP ? K : MLKEM_KPKE2_GROUP) : K + 1)> lds_all[KPKE2_WAVES];
+    __shared__ K2Lds<K + 1> lds_all[KPKE2_WAVES];   // K forward, then K + 1 inverse transforms in flight
     const int wv = wave_id(), l = lane_id(), h = l >> 5, t = l & 31, nb = k2_blk(t);   // nb: the lane's block of 8 coefficients in NAT layout
     const size_t item0 = 2 * ((size_t)blockIdx.x * KPKE2_WAVES + wv);     // wave-uniform: item bases live in SGPRs
     if (item0 >= n) return;
@@ -550,72 +546,63 @@ k_encrypt2(size_t n, const uint8_t* __restrict__ ek, size_t ek_stride, const uin
             k2_gamma(yh[b], tw.d0, tw.d1, yg[b]);
         }
     }
-    // ---- the K + 1 output polynomials, G at a time (ml_kem.c:854-904):
-    //        acc[a] = sum_b A^T[a][b] o y-hat[b] (a < K),  acc[K] = t-hat . y-hat ; G inverse transforms interleaved ;
+    // ---- the K + 1 output polynomials (ml_kem.c:854-904):
+    //        acc[a] = sum_b A^T[a][b] o y-hat[b] (a < K),  acc[K] = t-hat . y-hat ; the K + 1 inverse transforms interleaved ;
     //        u[a] = . + e1[a] -> Compress_du, ByteEncode_du ;  v = . + e2 + Decompress_1(m) -> Compress_dv, ByteEncode_dv
-    //      (all K + 1 at once would keep 8 (K + 1) accumulator registers live: G = 2 is what fits four waves per SIMD) ----
+    //      (running them two at a time to save accumulators keeps y-hat live across a transform and needs MORE registers:
+    //       156 instead of 138 at k = 3, profiles/r03_kpke_experiments.txt) ----
     uint32_t diff = 0;
     bool over = false;
-    auto group = [&](auto r0c, auto ngc) {
-        constexpr int R0 = decltype(r0c)::value, NG = decltype(ngc)::value;
-        v2f acc[NG][4];
-        K2Piece<DU> cu_ref[NG];
-        K2Piece<DV> cv_ref;
+    constexpr int NG = K + 1;
+    v2f acc[NG][4];
+    K2Piece<DU> cu_ref[NG];
+    K2Piece<DV> cv_ref;
 #pragma unroll
-        for (int g = 0; g < NG; g++) {
-            const int a = R0 + g;
+    for (int a = 0; a < NG; a++) {
 #pragma unroll
-            for (int j = 0; j < 4; j++) acc[g][j] = splat2(0.f);
+        for (int j = 0; j < 4; j++) acc[a][j] = splat2(0.f);
 #pragma unroll
-            for (int b = 0; b < K; b++) {
-                v2f av[4];
-                if (a < K) {
-                    k2_unpack16(a_all[a][b], av);
-                } else {
-                    k2_decode12(a_all[a][b].x, a_all[a][b].y, a_all[a][b].z, av);   // raw 12-bit values (F3)
-#pragma unroll
-                    for (int j = 0; j < 4; j++) over = over || (av[j].x >= F_Q) || (av[j].y >= F_Q);
-                }
-                k2_basemul_acc(acc[g], av, yh[b], yg[b]);
-            }
-        }
-        if constexpr (COMPARE) {                       // reference ciphertext pieces: in flight during the inverse transforms
-#pragma unroll
-            for (int g = 0; g < NG; g++) {
-                if (R0 + g < K) k2_piece_load<DU>(my_cin + (R0 + g) * 32 * DU, nb, cu_ref[g]);
-                else k2_piece_load<DV>(my_cin + K * 32 * DU, nb, cv_ref);
-            }
-        }
-        {
-            K2Tw twi;                                  // loaded here, not before the base-case products: 16 registers less at the peak
-            k2_twiddles_inv(twi, t);
-            k2_intt<NG>(acc, xch, h, t, twi);
-        }
-#pragma unroll
-        for (int g = 0; g < NG; g++) {
-            const int a = R0 + g;
-            K2CbdRaw<2> re;
-            re.w[0] = raw_e[a];
-            v2f e[4];
-            k2_cbd_eval<2>(re, e);
-#pragma unroll
-            for (int j = 0; j < 4; j++) acc[g][j] = acc[g][j] + e[j];
+        for (int b = 0; b < K; b++) {
+            v2f av[4];
             if (a < K) {
-                diff |= k2_emit<DU, COMPARE>(acc[g], nb, COMPARE ? nullptr : my_c + a * 32 * DU, cu_ref[g], valid);
+                k2_unpack16(a_all[a][b], av);
             } else {
+                k2_decode12(a_all[a][b].x, a_all[a][b].y, a_all[a][b].z, av);   // raw 12-bit values (F3)
 #pragma unroll
-                for (int j = 0; j < 4; j++)            // Decompress_1(1) = 1665
-                    acc[g][j] = acc[g][j] + v2f{((mb >> (2 * j)) & 1u) ? 1665.0f : 0.0f, ((mb >> (2 * j + 1)) & 1u) ? 1665.0f : 0.0f};
-                diff |= k2_emit<DV, COMPARE>(acc[g], nb, COMPARE ? nullptr : my_c + K * 32 * DU, cv_ref, valid);
+                for (int j = 0; j < 4; j++) over = over || (av[j].x >= F_Q) || (av[j].y >= F_Q);
             }
+            k2_basemul_acc(acc[a], av, yh[b], yg[b]);
         }
-    };
-    constexpr int G = MLKEM_KPKE2_GROUP < K + 1 ? MLKEM_KPKE2_GROUP : K + 1;
-    static_assert(G >= 1 && K + 1 <= 4 * G, "group size");
-    group(std::integral_constant<int, 0>{}, std::integral_constant<int, G>{});
-    if constexpr (K + 1 > G) group(std::integral_constant<int, G>{}, std::integral_constant<int, (K + 1 - G < G ? K + 1 - G : G)>{});
-    if constexpr (K + 1 > 2 * G) group(std::integral_constant<int, 2 * G>{}, std::integral_constant<int, (K + 1 - 2 * G < G ? K + 1 - 2 * G : G)>{});
-    if constexpr (K + 1 > 3 * G) group(std::integral_constant<int, 3 * G>{}, std::integral_constant<int, K + 1 - 3 * G>{});
+    }
+    if constexpr (COMPARE) {                           // reference ciphertext pieces: in flight during the inverse transforms
+#pragma unroll
+        for (int a = 0; a < NG; a++) {
+            if (a < K) k2_piece_load<DU>(my_cin + a * 32 * DU, nb, cu_ref[a]);
+            else k2_piece_load<DV>(my_cin + K * 32 * DU, nb, cv_ref);
+        }
+    }
+    {
+        K2Tw twi;                                      // loaded here, not before the base-case products: 16 registers less at the peak
+        k2_twiddles_inv(twi, t);
+        k2_intt<NG>(acc, xch, h, t, twi);
+    }
+#pragma unroll
+    for (int a = 0; a < NG; a++) {
+        K2CbdRaw<2> re;
+        re.w[0] = raw_e[a];
+        v2f e[4];
+        k2_cbd_eval<2>(re, e);
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[a][j] = acc[a][j] + e[j];
+        if (a < K) {
+            diff |= k2_emit<DU, COMPARE>(acc[a], nb, COMPARE ? nullptr : my_c + a * 32 * DU, cu_ref[a], valid);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; j++)                // Decompress_1(1) = 1665
+                acc[a][j] = acc[a][j] + v2f{((mb >> (2 * j)) & 1u) ? 1665.0f : 0.0f, ((mb >> (2 * j + 1)) & 1u) ? 1665.0f : 0.0f};
+            diff |= k2_emit<DV, COMPARE>(acc[a], nb, COMPARE ? nullptr : my_c + K * 32 * DU, cv_ref, valid);
+        }
+    }
     if (mod_status) {
         const unsigned long long bal = __ballot(over);
         const bool bad = ((bal >> (32 * h)) & 0xFFFFFFFFull) != 0;
