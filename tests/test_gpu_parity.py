@@ -609,10 +609,12 @@ def test_sha3_surface_nist_examples(pkg, engines, torch, golden):
     libc.free(h)
 
 
-def test_dev_calls_are_graph_capturable(pkg, torch, oracle):
+@pytest.mark.parametrize("chunk", (64, 1024), ids=("four-chunks", "one-chunk-forked"))
+def test_dev_calls_are_graph_capturable(pkg, torch, oracle, chunk):
     """The *_dev entry points neither allocate nor synchronise: a whole encaps+decaps pass is captured into a HIP graph
-    on a side stream and replayed on new inputs."""
-    e = pkg.MLKEM(768, device=0, chunk_items=64)
+    on a side stream and replayed on new inputs.  With one chunk per call the capture contains the fork to the context's side
+    stream and the join (SideFork); the context creates that stream with its first one-chunk call, here inside the capture."""
+    e = pkg.MLKEM(768, device=0, chunk_items=chunk)
     n = 200
     d, z = seeds("graph-d", n, 1), seeds("graph-z", n, 1)
     ek, dk = e.keygen(dev(torch, d), dev(torch, z))
