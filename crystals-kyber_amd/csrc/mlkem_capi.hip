@@ -168,6 +168,10 @@ int mlkem_ctx_create(mlkem_ctx** out, int device, size_t chunk_items) {
     c->ws.Kbar = c->ws.Kp + sz32;
     c->ws.cap = n;
     c->ws.hcap = hn;
+    if (const char* e = getenv("MLKEM_WIDE_HASH_ITEMS")) {   // 0: always the lane-sliced hash kernels
+        long long v = atoll(e);
+        if (v >= 0) c->ws.wide_max = (size_t)v;
+    }
     // fork / join events of one-chunk calls (SideFork, mlkem_pipeline.hpp); the side stream itself comes with the first such call
     // (ctx_arm_side).  MLKEM_SIDE_STREAM=0 keeps every call on the caller's stream; failing to create the events does the same.
     const char* se = getenv("MLKEM_SIDE_STREAM");

@@ -17,6 +17,7 @@
 #include "mlkem_rntt.hpp"
 #include "mlkem_kpke4.hpp"
 #include "mlkem_kpke2.hpp"
+#include "mlkem_wkeccak.hpp"
 #include <stdlib.h>
 #ifndef MLKEM_EMU
 #include <vector>
@@ -110,6 +111,8 @@ struct Workspace {
     uint32_t resume_cap = 0;    // records `resume` has room for
     size_t cap = 0;    // chunk capacity (items) of A / prf / leftover
     size_t hcap = 0;   // h-chunk capacity (items) of the 32-byte arrays
+    size_t wide_max = 1024;   // calls of at most this many items hash with one sponge per WAVE (mlkem_wkeccak.hpp: faster up to
+                              // 1024 items, slower from 2048, profiles/r03_batch_sweep.txt); env MLKEM_WIDE_HASH_ITEMS
     int fips = 0;      // 0: bit-identical to the reference (PRF, J on SHAKE128; no-op modulus check)
                        // 1: FIPS 203 conformant (PRF, J on SHAKE256; encaps reports status -4 for t-hat coefficients >= q)
 #ifndef MLKEM_EMU
@@ -243,7 +246,9 @@ inline void encaps_run(stream_t st, const ParamSet& p, size_t n, const uint8_t* 
     for (size_t h0 = 0; h0 < n; h0 += ws.hcap) {
         const size_t hn = min_sz(ws.hcap, n - h0);
         const uint8_t* r_h = r_user ? r_user + h0 * 32 : (const uint8_t*)ws.r;
-        if (!r_user)
+        if (!r_user && n <= ws.wide_max)   // small call: one sponge per wave, a chain of ~4.5 us permutations instead of ~10.5
+            launch("k_hash_encaps", k_hash_encaps_w<K>, hn, WAVE, st, hn, ek + h0 * p.ek_len, m + h0 * 32, Kout + h0 * 32, ws.r);
+        else if (!r_user)
             launch("k_hash_encaps", k_hash_encaps<K>, ceil_div(hn, WAVE), WAVE, st, hn, ek + h0 * p.ek_len, m + h0 * 32, Kout + h0 * 32, ws.r);
         for (size_t c0 = 0; c0 < hn; c0 += ws.cap) {
             const size_t cn = min_sz(ws.cap, hn - c0), i0 = h0 + c0;
@@ -283,6 +288,16 @@ inline void decaps_run(stream_t st, const ParamSet& p, size_t n, const uint8_t* 
         decrypt_launch<K, DU, DV>(st, hn, dkh, (size_t)p.dk_len, ch, ws.m);
         int32_t* sth = (hash_check && status) ? status + h0 : (int32_t*)nullptr;
         const size_t hgrid = ceil_div(hn, WAVE);
+        if (n <= ws.wide_max) {   // small call: one sponge per wave (mlkem_wkeccak.hpp)
+            if (hash_check && !ws.fips)
+                launch("k_hash_decaps", k_hash_decaps_w<K, CLEN, true, 168>, 2 * hn, WAVE, st, hn, dkh, ch, (const uint8_t*)ws.m, ws.Kp, ws.r, ws.Kbar, sth, (size_t)p.dk_len);
+            else if (!ws.fips)
+                launch("k_hash_decaps", k_hash_decaps_w<K, CLEN, false, 168>, hn, WAVE, st, hn, dkh, ch, (const uint8_t*)ws.m, ws.Kp, ws.r, ws.Kbar, sth, (size_t)p.dk_len);
+            else if (hash_check)
+                launch("k_hash_decaps", k_hash_decaps_w<K, CLEN, true, 136>, 2 * hn, WAVE, st, hn, dkh, ch, (const uint8_t*)ws.m, ws.Kp, ws.r, ws.Kbar, sth, (size_t)p.dk_len);
+            else
+                launch("k_hash_decaps", k_hash_decaps_w<K, CLEN, false, 136>, hn, WAVE, st, hn, dkh, ch, (const uint8_t*)ws.m, ws.Kp, ws.r, ws.Kbar, sth, (size_t)p.dk_len);
+        } else
         if (hash_check && !ws.fips)
             launch("k_hash_decaps", k_hash_decaps<K, CLEN, true, 168>, 2 * hgrid, WAVE, st, hn, dkh, ch, (const uint8_t*)ws.m, ws.Kp, ws.r, ws.Kbar, sth, (size_t)p.dk_len);
         else if (!ws.fips)

@@ -471,3 +471,36 @@ def test_emu_two_items_per_wave_every_batch_parity_and_piece_compare(emu, oracle
     Kd2 = np.zeros((n, 32), np.uint8)
     assert emu.emu_decaps(pset, C.c_size_t(n), p8(dkr), p8(c), p8(Kd2), st.ctypes.data_as(C.POINTER(C.c_int32)), 1) == 0
     assert (Kd2 == K).all()                            # and the untouched ciphertexts accepted
+
+
+@pytest.mark.parametrize("pset,fips", ((768, 0), (1024, 1)))
+def test_emu_one_sponge_per_wave_hash_kernels(emu, oracle, pset, fips):
+    """mlkem_wkeccak.hpp (calls of at most `wide_max` items): H(ek) -> G and the dk hash check | J -> G with one sponge per
+    wave, cross-lane fetches emulated by shuffles.  Three items: keygen (lane-sliced kernels) -> encaps -> decaps of the
+    untouched, a tampered ciphertext and a corrupted stored H(ek), bit for bit against the oracle."""
+    n = 3
+    ekl, dkl, cl = SIZES[pset]
+    emu.emu_conformance(fips)
+    emu.emu_wide_hash(C.c_size_t(16))
+    try:
+        d, z, m = seeds("wk-d", n, pset), seeds("wk-z", n, pset), seeds("wk-m", n, pset)
+        ek, dk = oracle.keygen(pset, d, z)
+        c, K = np.zeros((n, cl), np.uint8), np.zeros((n, 32), np.uint8)
+        oracle.set_conformance(bool(fips))
+        assert emu.emu_encaps(pset, C.c_size_t(n), p8(ek), p8(m), p8(c), p8(K), None) == 0
+        c_o, K_o = oracle.encaps(pset, ek, m)
+        assert (c == c_o).all() and (K == K_o).all()
+        cb, dkb = c.copy(), dk.copy()
+        cb[1, 40] ^= 4                                     # item 1: implicit rejection
+        dkb[2, dkl - 40] ^= 1                              # item 2: stored H(ek) corrupted -> status -5
+        Kd, st = np.zeros((n, 32), np.uint8), np.ones(n, np.int32)
+        assert emu.emu_decaps(pset, C.c_size_t(n), p8(dkb), p8(cb), p8(Kd), st.ctypes.data_as(C.POINTER(C.c_int32)), 1) == 0
+        Kd_o, st_o = oracle.decaps(pset, dkb, cb)
+        assert st.tolist() == [0, 0, -5] and (st == st_o).all(), (st, st_o)
+        assert (Kd[st_o == 0] == Kd_o[st_o == 0]).all()
+        assert (Kd[2] == oracle.decaps_internal(pset, dkb[2], cb[2])).all()   # the -5 row still carries Decaps_internal's key (G on the stored h)
+        assert (Kd[0] == K[0]).all() and (Kd[1] != K[1]).any()
+    finally:
+        emu.emu_wide_hash(C.c_size_t(0))
+        emu.emu_conformance(0)
+        oracle.set_conformance(False)
