@@ -336,14 +336,16 @@ def test_every_ciphertext_byte_takes_part_in_the_compare(pkg, torch, oracle, pse
 
 
 # ---- calls of one chunk: matrix sampling on the context's side stream ------------------------------------------------------
-@pytest.mark.parametrize("env", ({}, {"MLKEM_SIDE_STREAM": "0"}), ids=("side-stream", "one-stream"))
+@pytest.mark.parametrize("env", ({}, {"MLKEM_SIDE_STREAM": "0"}, {"MLKEM_WIDE_HASH_ITEMS": "0"}, {"MLKEM_WIDE_HASH_ITEMS": "100000"}),
+                         ids=("side-stream", "one-stream", "lane-sliced-hashes", "one-sponge-per-wave-hashes"))
 @pytest.mark.parametrize("pset,n", ((768, 1000), (512, 3), (1024, 130)))
 def test_single_chunk_calls_keep_their_results_with_and_without_the_side_stream(pkg, torch, oracle, env, monkeypatch, pset, n):
     """A call that fits one chunk samples A-hat on the context's side stream while H(ek) / G (encaps) or Decrypt and the
     three sponges (decaps) run on the caller's stream (SideFork, mlkem_pipeline.hpp).  Six rounds of keygen -> encaps ->
     decaps with different data are queued back to back WITHOUT a synchronisation in between: a matrix sampled too early
     (before the previous call's arithmetic has read the scratch) or joined too late would change bytes.  Same bytes with the
-    side stream disabled."""
+    side stream disabled, and with either family of hash kernels forced for every size (by default calls of at most 1024 items
+    hash with one sponge per wavefront, mlkem_wkeccak.hpp, larger ones with one sponge per lane)."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     e = pkg.MLKEM(pset, device=0, chunk_items=1024)
