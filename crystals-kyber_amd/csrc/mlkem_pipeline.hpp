@@ -237,7 +237,9 @@ inline void keygen_run(stream_t st, const ParamSet& p, size_t n, const uint8_t* 
                 launch("k_keygen", k_keygen2<K, ETA1, false>, kgrid, WAVE * KPKE2_WAVES, st, cn, (const uint16_t*)ws.A, (const uint8_t*)ws.prf,
                        (const uint8_t*)(ws.rho + c0 * 32), ek + i0 * p.ek_len, dk + i0 * dk_len);
         }
-        if (kem)
+        if (kem && n <= ws.wide_max)   // small call: one sponge per wave (mlkem_wkeccak.hpp)
+            launch("k_hash_keygen_fin", k_hash_keygen_fin_w<K>, hn, WAVE, st, hn, (const uint8_t*)(ek + h0 * p.ek_len), z + h0 * 32, dk + h0 * p.dk_len);
+        else if (kem)
             launch("k_hash_keygen_fin", k_hash_keygen_fin<K>, ceil_div(hn, WAVE), WAVE, st, hn, (const uint8_t*)(ek + h0 * p.ek_len),
                    z + h0 * 32, dk + h0 * p.dk_len);
     }

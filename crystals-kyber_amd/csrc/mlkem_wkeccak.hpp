@@ -145,6 +145,26 @@ __global__ void __launch_bounds__(WAVE) k_hash_encaps_w(size_t n, const uint8_t*
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_hash_keygen_fin_w — KeyGen_internal's dk tail (ml_kem.c:1065-1077), one item per wave: dk[768k+32 ..] = H(ek) ; dk[768k+64 ..] = z
+// ------------------------------------------------------------------------------------------------
+template <int K>
+__global__ void __launch_bounds__(WAVE) k_hash_keygen_fin_w(size_t n, const uint8_t* __restrict__ ek, const uint8_t* __restrict__ z,
+                                                            uint8_t* __restrict__ dk) {
+    constexpr unsigned EK = 384 * K + 32, DK = 768 * K + 96;
+    const size_t item = blockIdx.x;
+    if (item >= n) return;
+    const unsigned L = (unsigned)lane_id();
+    WkLane c;
+    wk_lane_init(c);
+    WkState a;
+    wk_absorb<136, 0x06>(a, c, ek + item * EK, EK, ek, EK);
+    uint2 o;
+    o.x = a.lo; o.y = a.hi;
+    if (L >= 4 && L < 8) o = reinterpret_cast<const uint2*>(z + item * 32)[L - 4];
+    if (L < 8) reinterpret_cast<uint2*>(dk + item * DK + 768 * K + 32)[L] = o;   // h (lanes 0..3) then z (lanes 4..7): 64 contiguous bytes
+}
+
+// ------------------------------------------------------------------------------------------------
 // k_hash_decaps_w — KEM_Decaps' hash check and Decaps_internal's hashing (ml_kem.c:1336-1350, :1187-1202), one sponge per
 // wave: blocks [0, n) run J(z || c) and then G(m' || h); with HASH_CHECK blocks [n, 2 n) run H(dk.ek) against dk.h.
 // Arguments as k_hash_decaps.

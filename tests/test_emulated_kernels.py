@@ -476,7 +476,7 @@ def test_emu_two_items_per_wave_every_batch_parity_and_piece_compare(emu, oracle
 @pytest.mark.parametrize("pset,fips", ((768, 0), (1024, 1)))
 def test_emu_one_sponge_per_wave_hash_kernels(emu, oracle, pset, fips):
     """mlkem_wkeccak.hpp (calls of at most `wide_max` items): H(ek) -> G and the dk hash check | J -> G with one sponge per
-    wave, cross-lane fetches emulated by shuffles.  Three items: keygen (lane-sliced kernels) -> encaps -> decaps of the
+    wave, cross-lane fetches emulated by shuffles.  Three items: keygen (its dk tail H(ek) || z per wave) -> encaps -> decaps of the
     untouched, a tampered ciphertext and a corrupted stored H(ek), bit for bit against the oracle."""
     n = 3
     ekl, dkl, cl = SIZES[pset]
@@ -484,9 +484,12 @@ def test_emu_one_sponge_per_wave_hash_kernels(emu, oracle, pset, fips):
     emu.emu_wide_hash(C.c_size_t(16))
     try:
         d, z, m = seeds("wk-d", n, pset), seeds("wk-z", n, pset), seeds("wk-m", n, pset)
-        ek, dk = oracle.keygen(pset, d, z)
-        c, K = np.zeros((n, cl), np.uint8), np.zeros((n, 32), np.uint8)
         oracle.set_conformance(bool(fips))
+        ek, dk = oracle.keygen(pset, d, z)
+        ek_e, dk_e = np.zeros((n, ekl), np.uint8), np.zeros((n, dkl), np.uint8)
+        assert emu.emu_keygen(pset, C.c_size_t(n), p8(d), p8(z), p8(ek_e), p8(dk_e)) == 0     # dk tail: H(ek) per wave, then z
+        assert (ek_e == ek).all() and (dk_e == dk).all()
+        c, K = np.zeros((n, cl), np.uint8), np.zeros((n, 32), np.uint8)
         assert emu.emu_encaps(pset, C.c_size_t(n), p8(ek), p8(m), p8(c), p8(K), None) == 0
         c_o, K_o = oracle.encaps(pset, ek, m)
         assert (c == c_o).all() and (K == K_o).all()
