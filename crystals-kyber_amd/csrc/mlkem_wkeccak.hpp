@@ -1,18 +1,20 @@
 // mlkem_wkeccak.hpp — one sponge per HALF-WAVE (two per wavefront): the hash kernels of small batches.
 //
 // The lane-sliced kernels (mlkem_kernels.hpp: one sponge per SIMD lane) are built for throughput; a call of a few thousand
-// items does not fill the GPU with them and waits for the dependency chain of ONE lane: 9-10 permutations of 4320 instructions,
-// ~10.5 us each for a lone wave.  Here a wave carries TWO sponges, one per 32-lane half; Keccak lane (x, y) of a state lives in
-// SIMD lane x + 5 y of its half (25 of 32 lanes; one 64-bit Keccak lane = two VGPRs per SIMD lane), a round is ~40 instructions, and theta / pi / chi fetch their operands from
-// other lanes with ds_bpermute_b32 (18 per round, in three dependent groups):
+// items does not fill the GPU with them and waits for the dependency chain of ONE lane: 9-10 permutations of 4320
+// instructions, ~10.5 us each for a lone wave.  Here a wave carries TWO sponges, one per 32-lane half; Keccak lane (x, y) of a
+// state lives in SIMD lane x + 5 y of its half (25 of 32 lanes; one 64-bit Keccak lane = two VGPRs per SIMD lane), a round is
+// ~40 instructions, and theta / pi / chi fetch their operands from other lanes with ds_bpermute_b32 (18 per round, in three
+// dependent groups):
 //   theta   C[x] = xor of the column: four fetches from (x, y + k) ; D needs C[x - 1], C[x + 1]: two more ;
 //   rho     a per-lane 64-bit rotate (two v_alignbit with the lane's own shift, halves pre-swapped for offsets >= 32) ;
 //   pi+chi  lane (x', y') fetches the rotated lanes that pi maps to (x', y'), (x' + 1, y'), (x' + 2, y') and combines them ;
 //   iota    lane 0.
-// 5.3 us per permutation of a lone wave instead of 10.5: H(ek) -> G 0.107 -> 0.053 ms, the Decaps sponges 0.095 -> 0.047 ms at
-// 64 items; faster up to 2048 items per call, slower from 4096 (profiles/r03_batch_sweep.txt), hence Workspace::wide_max.  Message bytes map 1:1: SIMD lane L
-// owns bytes [8 L, 8 L + 8) of every rate block, so absorbing is one 8-byte load per lane and block.  All message lengths on
-// this path are multiples of 8 (ek, z || c, m || h).  Follows sha3.c:15-216 (permutation), :257-330 (sponge) of the reference.
+// 5.3 us per permutation of a lone wave instead of 10.5: H(ek) -> G 0.107 -> 0.053 ms, the Decaps sponges 0.095 -> 0.047 ms
+// at 64 items; faster up to 2048 items per call, slower from 4096 (profiles/r03_batch_sweep.txt), hence Workspace::wide_max.
+// Message bytes map 1:1: lane L of a half owns bytes [8 L, 8 L + 8) of every rate block, so absorbing is one 8-byte load per
+// lane and block.  All message lengths on this path are multiples of 8 (ek, z || c, m || h).  Follows sha3.c:15-216
+// (permutation), :257-330 (sponge) of the reference.
 #pragma once
 #include "mlkem_kernels.hpp"
 
