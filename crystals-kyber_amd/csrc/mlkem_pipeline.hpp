@@ -238,7 +238,7 @@ inline void keygen_run(stream_t st, const ParamSet& p, size_t n, const uint8_t* 
                        (const uint8_t*)(ws.rho + c0 * 32), ek + i0 * p.ek_len, dk + i0 * dk_len);
         }
         if (kem && n <= ws.wide_max)   // small call: one sponge per wave (mlkem_wkeccak.hpp)
-            launch("k_hash_keygen_fin", k_hash_keygen_fin_w<K>, ceil_div(hn, 2), WAVE, st, hn, (const uint8_t*)(ek + h0 * p.ek_len), z + h0 * 32, dk + h0 * p.dk_len);
+            launch("k_hash_keygen_fin", k_hash_keygen_fin_w<K>, hn, WAVE, st, hn, (const uint8_t*)(ek + h0 * p.ek_len), z + h0 * 32, dk + h0 * p.dk_len);
         else if (kem)
             launch("k_hash_keygen_fin", k_hash_keygen_fin<K>, ceil_div(hn, WAVE), WAVE, st, hn, (const uint8_t*)(ek + h0 * p.ek_len),
                    z + h0 * 32, dk + h0 * p.dk_len);
@@ -256,7 +256,7 @@ inline void encaps_run(stream_t st, const ParamSet& p, size_t n, const uint8_t* 
         const size_t hn = min_sz(ws.hcap, n - h0);
         const uint8_t* r_h = r_user ? r_user + h0 * 32 : (const uint8_t*)ws.r;
         if (!r_user && n <= ws.wide_max)   // small call: one sponge per wave, a chain of ~4.5 us permutations instead of ~10.5
-            launch("k_hash_encaps", k_hash_encaps_w<K>, ceil_div(hn, 2), WAVE, st, hn, ek + h0 * p.ek_len, m + h0 * 32, Kout + h0 * 32, ws.r);
+            launch("k_hash_encaps", k_hash_encaps_w<K>, hn, WAVE, st, hn, ek + h0 * p.ek_len, m + h0 * 32, Kout + h0 * 32, ws.r);
         else if (!r_user)
             launch("k_hash_encaps", k_hash_encaps<K>, ceil_div(hn, WAVE), WAVE, st, hn, ek + h0 * p.ek_len, m + h0 * 32, Kout + h0 * 32, ws.r);
         for (size_t c0 = 0; c0 < hn; c0 += ws.cap) {
@@ -299,13 +299,13 @@ inline void decaps_run(stream_t st, const ParamSet& p, size_t n, const uint8_t* 
         const size_t hgrid = ceil_div(hn, WAVE);
         if (n <= ws.wide_max) {   // small call: one sponge per wave (mlkem_wkeccak.hpp)
             if (hash_check && !ws.fips)
-                launch("k_hash_decaps", k_hash_decaps_w<K, CLEN, true, 168>, 2 * ceil_div(hn, 2), WAVE, st, hn, dkh, ch, (const uint8_t*)ws.m, ws.Kp, ws.r, ws.Kbar, sth, (size_t)p.dk_len);
+                launch("k_hash_decaps", k_hash_decaps_w<K, CLEN, true, 168>, 2 * hn, WAVE, st, hn, dkh, ch, (const uint8_t*)ws.m, ws.Kp, ws.r, ws.Kbar, sth, (size_t)p.dk_len);
             else if (!ws.fips)
-                launch("k_hash_decaps", k_hash_decaps_w<K, CLEN, false, 168>, ceil_div(hn, 2), WAVE, st, hn, dkh, ch, (const uint8_t*)ws.m, ws.Kp, ws.r, ws.Kbar, sth, (size_t)p.dk_len);
+                launch("k_hash_decaps", k_hash_decaps_w<K, CLEN, false, 168>, hn, WAVE, st, hn, dkh, ch, (const uint8_t*)ws.m, ws.Kp, ws.r, ws.Kbar, sth, (size_t)p.dk_len);
             else if (hash_check)
-                launch("k_hash_decaps", k_hash_decaps_w<K, CLEN, true, 136>, 2 * ceil_div(hn, 2), WAVE, st, hn, dkh, ch, (const uint8_t*)ws.m, ws.Kp, ws.r, ws.Kbar, sth, (size_t)p.dk_len);
+                launch("k_hash_decaps", k_hash_decaps_w<K, CLEN, true, 136>, 2 * hn, WAVE, st, hn, dkh, ch, (const uint8_t*)ws.m, ws.Kp, ws.r, ws.Kbar, sth, (size_t)p.dk_len);
             else
-                launch("k_hash_decaps", k_hash_decaps_w<K, CLEN, false, 136>, ceil_div(hn, 2), WAVE, st, hn, dkh, ch, (const uint8_t*)ws.m, ws.Kp, ws.r, ws.Kbar, sth, (size_t)p.dk_len);
+                launch("k_hash_decaps", k_hash_decaps_w<K, CLEN, false, 136>, hn, WAVE, st, hn, dkh, ch, (const uint8_t*)ws.m, ws.Kp, ws.r, ws.Kbar, sth, (size_t)p.dk_len);
         } else
         if (hash_check && !ws.fips)
             launch("k_hash_decaps", k_hash_decaps<K, CLEN, true, 168>, 2 * hgrid, WAVE, st, hn, dkh, ch, (const uint8_t*)ws.m, ws.Kp, ws.r, ws.Kbar, sth, (size_t)p.dk_len);
