@@ -172,6 +172,10 @@ int mlkem_ctx_create(mlkem_ctx** out, int device, size_t chunk_items) {
         long long v = atoll(e);
         if (v >= 0) c->ws.wide_max = (size_t)v;
     }
+    if (const char* e = getenv("MLKEM_SMALL_ITEMS")) {       // 0: never the one-workgroup-per-item kernels
+        long long v = atoll(e);
+        if (v >= 0) c->ws.small_max = (size_t)v;
+    }
     // fork / join events of one-chunk calls (SideFork, mlkem_pipeline.hpp); the side stream itself comes with the first such call
     // (ctx_arm_side).  MLKEM_SIDE_STREAM=0 keeps every call on the caller's stream; failing to create the events does the same.
     const char* se = getenv("MLKEM_SIDE_STREAM");

@@ -7,7 +7,9 @@
 //   k_sample      lane = one SHAKE128 sponge; role XOF -> SampleNTT rejection sampling (ml_kem.c:189) with
 //                 an LDS ring per lane flushed in aligned 128-byte chunks; role PRF -> raw PRF bytes (ml_kem.c:496)
 //                 (its three-block fast path lives in mlkem_sampler.hpp)
-// The wave-per-instance polynomial kernels (k_keygen / k_encrypt / k_decrypt, stand-alone NTT) are in mlkem_arith.hpp.
+// The polynomial kernels: K-PKE.KeyGen / Encrypt two items per wave in mlkem_kpke2.hpp (k_keygen2, k_encrypt2), K-PKE.Decrypt four
+// items per wave in mlkem_kpke4.hpp (k_decrypt4), the stand-alone transforms in mlkem_rntt.hpp, the other primitives in mlkem_arith.hpp;
+// one-workgroup-per-item kernels for small calls in mlkem_small.hpp (on the one-sponge-per-wave Keccak of mlkem_wkeccak.hpp).
 //
 // No kernel uses a workgroup barrier: every wave is independent, LDS is carved per wave.
 #pragma once

@@ -483,23 +483,23 @@ __device__ __forceinline__ uint32_t k2_emit(const v2f (&p)[4], int t, uint8_t* o
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_encrypt2 — K-PKE.Encrypt (ml_kem.c:776-936) for two items per wave, given A^T and the PRF bytes of the sampler.
+// k_encrypt2 / encrypt2_body — K-PKE.Encrypt (ml_kem.c:776-936) for two items per wave, given A^T and the PRF bytes of the sampler.
 //   COMPARE = false : write c                                   (Encaps_internal, ml_kem.c:1127)
 //   COMPARE = true  : compare c' with c, K = (c == c') ? K' : Kbar (Decaps_internal, ml_kem.c:1206-1215)
-// Arguments as k_encrypt (mlkem_arith.hpp).
+// ek: packed keys, ek_stride bytes apart (0: one shared key) ; A: matrices, a_stride uint16 apart (0: one shared matrix) ;
+// prf: (2K+1) rows of PS bytes per item ; mod_status (may be null): -4 where a t-hat coefficient is >= q (FIPS 203 mode).
 // ------------------------------------------------------------------------------------------------
+// encrypt2_body: the work of ONE wave -- items item0 and item0 + 1 of the n the pointers describe; `xch` = the wave's exchange
+// buffers (K2Lds<K + 1>::xch).  Called by k_encrypt2 (batches) and by the one-workgroup-per-item kernels of mlkem_small.hpp.
 template <int K, int ETA1, int DU, int DV, bool COMPARE>
-__global__ void __launch_bounds__(WAVE * KPKE2_WAVES, kpke2_minwaves(K))
-k_encrypt2(size_t n, const uint8_t* __restrict__ ek, size_t ek_stride, const uint8_t* __restrict__ msg, const uint16_t* __restrict__ A,
-           const uint8_t* __restrict__ prf, uint8_t* __restrict__ c_out, const uint8_t* __restrict__ c_in, const uint8_t* __restrict__ Kp,
-           const uint8_t* __restrict__ Kbar, uint8_t* __restrict__ Kout, int32_t* __restrict__ mod_status, size_t a_stride) {
-    __shared__ K2Lds<K + 1> lds_all[KPKE2_WAVES];   // K forward, then K + 1 inverse transforms in flight
-    const int wv = wave_id(), l = lane_id(), h = l >> 5, t = l & 31, nb = k2_blk(t);   // nb: the lane's block of 8 coefficients in NAT layout
-    const size_t item0 = 2 * ((size_t)blockIdx.x * KPKE2_WAVES + wv);     // wave-uniform: item bases live in SGPRs
-    if (item0 >= n) return;
+__device__ __forceinline__ void
+encrypt2_body(float2 (*xch)[2][128], size_t item0, size_t n, const uint8_t* __restrict__ ek, size_t ek_stride, const uint8_t* __restrict__ msg,
+              const uint16_t* __restrict__ A, const uint8_t* __restrict__ prf, uint8_t* __restrict__ c_out, const uint8_t* __restrict__ c_in,
+              const uint8_t* __restrict__ Kp, const uint8_t* __restrict__ Kbar, uint8_t* __restrict__ Kout, int32_t* __restrict__ mod_status,
+              size_t a_stride) {
+    const int l = lane_id(), h = l >> 5, t = l & 31, nb = k2_blk(t);   // nb: the lane's block of 8 coefficients in NAT layout
     const bool valid = item0 + (size_t)h < n;          // n odd: the upper half of the last wave redoes item n - 1, stores nothing
     const unsigned hh = valid ? (unsigned)h : 0u;      // the half's item = item0 + hh; per-lane offsets are 32-bit
-    float2 (*xch)[2][128] = lds_all[wv].xch;
     constexpr unsigned PS = (ETA1 == 3) ? 192 : 128, CLEN = 32 * (DU * K + DV), PRFLEN = (2 * K + 1) * PS;
     // wave-uniform bases (SGPRs) + 32-bit per-lane offsets: the upper half's item lies one stride further
     const uint8_t* my_prf = prf + item0 * (size_t)PRFLEN + (size_t)(hh * PRFLEN);
@@ -620,6 +620,17 @@ k_encrypt2(size_t n, const uint8_t* __restrict__ ek, size_t ek_stride, const uin
         }
     }
 }
+template <int K, int ETA1, int DU, int DV, bool COMPARE>
+__global__ void __launch_bounds__(WAVE * KPKE2_WAVES, kpke2_minwaves(K))
+k_encrypt2(size_t n, const uint8_t* __restrict__ ek, size_t ek_stride, const uint8_t* __restrict__ msg, const uint16_t* __restrict__ A,
+           const uint8_t* __restrict__ prf, uint8_t* __restrict__ c_out, const uint8_t* __restrict__ c_in, const uint8_t* __restrict__ Kp,
+           const uint8_t* __restrict__ Kbar, uint8_t* __restrict__ Kout, int32_t* __restrict__ mod_status, size_t a_stride) {
+    __shared__ K2Lds<K + 1> lds_all[KPKE2_WAVES];   // K forward, then K + 1 inverse transforms in flight
+    const int wv = wave_id();
+    const size_t item0 = 2 * ((size_t)blockIdx.x * KPKE2_WAVES + wv);     // wave-uniform: item bases live in SGPRs
+    if (item0 >= n) return;
+    encrypt2_body<K, ETA1, DU, DV, COMPARE>(lds_all[wv].xch, item0, n, ek, ek_stride, msg, A, prf, c_out, c_in, Kp, Kbar, Kout, mod_status, a_stride);
+}
 
 // canonical representatives in [0, q) of the lane's pairs (any |x| <= 2^24), as integers
 __device__ __forceinline__ void k2_canon(const v2f (&p)[4], unsigned (&c)[8]) {
@@ -636,19 +647,17 @@ __device__ __forceinline__ void k2_canon(const v2f (&p)[4], unsigned (&c)[8]) {
 // ------------------------------------------------------------------------------------------------
 // k_keygen2 — K-PKE.KeyGen after G and sampling (ml_kem.c:696-756) + the plain copies of KeyGen_internal
 // (ml_kem.c:1054-1062) for two items per wave: ek = Enc12(t-hat) || rho ; dk = Enc12(s-hat) || ek || [H(ek)] || [z]
-// Arguments as k_keygen (mlkem_arith.hpp).
+// A: the sampled matrix (K*K polynomials per item, uint16, natural order) ; prf: 2K rows of PS bytes per item (s then e) ;
+// rho: 32 bytes per item.
 // ------------------------------------------------------------------------------------------------
+// keygen2_body: the work of one wave (items item0, item0 + 1); `xch` = the wave's K2Lds<K>::xch
 template <int K, int ETA1, bool KEM_DK>
-__global__ void __launch_bounds__(WAVE * KPKE2_WAVES, K == 2 ? kpke2_minwaves(2) : kpke2_minwaves(K + 1))   // s-hat AND e-hat stay in registers
-k_keygen2(size_t n, const uint16_t* __restrict__ A, const uint8_t* __restrict__ prf, const uint8_t* __restrict__ rho,
-          uint8_t* __restrict__ ek, uint8_t* __restrict__ dk) {
-    __shared__ K2Lds<K> lds_all[KPKE2_WAVES];
-    const int wv = wave_id(), l = lane_id(), h = l >> 5, t = l & 31, nb = k2_blk(t);
-    const size_t item0 = 2 * ((size_t)blockIdx.x * KPKE2_WAVES + wv);
-    if (item0 >= n) return;
+__device__ __forceinline__ void
+keygen2_body(float2 (*xch)[2][128], size_t item0, size_t n, const uint16_t* __restrict__ A, const uint8_t* __restrict__ prf,
+             const uint8_t* __restrict__ rho, uint8_t* __restrict__ ek, uint8_t* __restrict__ dk) {
+    const int l = lane_id(), h = l >> 5, t = l & 31, nb = k2_blk(t);
     const bool valid = item0 + (size_t)h < n;
     const unsigned hh = valid ? (unsigned)h : 0u;
-    float2 (*xch)[2][128] = lds_all[wv].xch;
     constexpr unsigned PS = (ETA1 == 3) ? 192 : 128, EK = 384 * K + 32, DK = KEM_DK ? 768 * K + 96 : 384 * K, PRFLEN = 2 * K * PS;
     const uint8_t* my_prf = prf + item0 * (size_t)PRFLEN + (size_t)(hh * PRFLEN);
     const uint16_t* my_A = A + item0 * (size_t)(K * K * 256) + (size_t)(hh * (unsigned)(K * K * 256));
@@ -719,6 +728,16 @@ k_keygen2(size_t n, const uint16_t* __restrict__ A, const uint8_t* __restrict__ 
         reinterpret_cast<uint32_t*>(my_ek + 384 * K)[t] = rho_w;
         if constexpr (KEM_DK) reinterpret_cast<uint32_t*>(my_dk + 768 * K)[t] = rho_w;
     }
+}
+template <int K, int ETA1, bool KEM_DK>
+__global__ void __launch_bounds__(WAVE * KPKE2_WAVES, K == 2 ? kpke2_minwaves(2) : kpke2_minwaves(K + 1))   // s-hat AND e-hat stay in registers
+k_keygen2(size_t n, const uint16_t* __restrict__ A, const uint8_t* __restrict__ prf, const uint8_t* __restrict__ rho,
+          uint8_t* __restrict__ ek, uint8_t* __restrict__ dk) {
+    __shared__ K2Lds<K> lds_all[KPKE2_WAVES];
+    const int wv = wave_id();
+    const size_t item0 = 2 * ((size_t)blockIdx.x * KPKE2_WAVES + wv);
+    if (item0 >= n) return;
+    keygen2_body<K, ETA1, KEM_DK>(lds_all[wv].xch, item0, n, A, prf, rho, ek, dk);
 }
 
 }   // namespace mlkem

@@ -102,13 +102,11 @@ __device__ __forceinline__ void gamma_products(const float (&y)[8], const Tw z10
 // ------------------------------------------------------------------------------------------------
 // k_decrypt4 — m' = ByteEncode_1(Compress_1(v - InverseNTT(s-hat . NTT(u)))) for four items per wave
 // ------------------------------------------------------------------------------------------------
+// decrypt4_body: the work of one wave = items 4 quad .. 4 quad + 3 of the n the pointers describe
 template <int K, int DU, int DV>
-__global__ void __launch_bounds__(64 * KPKE4_WAVES, kpke4_minwaves(K)) k_decrypt4(size_t n, const uint8_t* __restrict__ dk, size_t dk_stride,
-                                                                const uint8_t* __restrict__ c, uint8_t* __restrict__ m_out) {
-    const int wv = wave_id();
+__device__ __forceinline__ void decrypt4_body(size_t quad, size_t n, const uint8_t* __restrict__ dk, size_t dk_stride,
+                                              const uint8_t* __restrict__ c, uint8_t* __restrict__ m_out) {
     const RnttLane a = rntt_lane();
-    const size_t quad = (size_t)blockIdx.x * KPKE4_WAVES + wv;
-    if (4 * quad >= n) return;
     // rows beyond n (n % 4 != 0) redo item n - 1 and store nothing
     const size_t item_raw = 4 * quad + (size_t)a.p, item = item_raw < n ? item_raw : n - 1;
     constexpr unsigned CLEN = 32 * (DU * K + DV);
@@ -159,6 +157,13 @@ __global__ void __launch_bounds__(64 * KPKE4_WAVES, kpke4_minwaves(K)) k_decrypt
         m_out[item * 32 + (size_t)a.m] = (uint8_t)b_lo;
         m_out[item * 32 + 16 + (size_t)a.m] = (uint8_t)b_hi;
     }
+}
+template <int K, int DU, int DV>
+__global__ void __launch_bounds__(64 * KPKE4_WAVES, kpke4_minwaves(K)) k_decrypt4(size_t n, const uint8_t* __restrict__ dk, size_t dk_stride,
+                                                                const uint8_t* __restrict__ c, uint8_t* __restrict__ m_out) {
+    const size_t quad = (size_t)blockIdx.x * KPKE4_WAVES + wave_id();
+    if (4 * quad >= n) return;
+    decrypt4_body<K, DU, DV>(quad, n, dk, dk_stride, c, m_out);
 }
 
 }   // namespace mlkem

@@ -18,6 +18,7 @@
 #include "mlkem_kpke4.hpp"
 #include "mlkem_kpke2.hpp"
 #include "mlkem_wkeccak.hpp"
+#include "mlkem_small.hpp"
 #include <stdlib.h>
 #ifndef MLKEM_EMU
 #include <vector>
@@ -113,6 +114,8 @@ struct Workspace {
     size_t hcap = 0;   // h-chunk capacity (items) of the 32-byte arrays
     size_t wide_max = 2048;   // calls of at most this many items hash with one sponge per HALF-WAVE (mlkem_wkeccak.hpp: faster
                               // up to 2048 items, slower from 4096, profiles/r03_batch_sweep.txt); env MLKEM_WIDE_HASH_ITEMS
+    size_t small_max = 256;   // calls of at most this many items run as ONE launch, one workgroup per item (mlkem_small.hpp);
+                              // env MLKEM_SMALL_ITEMS (0: never)
     int fips = 0;      // 0: bit-identical to the reference (PRF, J on SHAKE128; no-op modulus check)
                        // 1: FIPS 203 conformant (PRF, J on SHAKE256; encaps reports status -4 for t-hat coefficients >= q)
 #ifndef MLKEM_EMU
@@ -223,6 +226,12 @@ inline void keygen_run(stream_t st, const ParamSet& p, size_t n, const uint8_t* 
                        const Workspace& ws) {
     const bool kem = z != nullptr;
     const size_t dk_len = kem ? (size_t)p.dk_len : (size_t)(384 * K);
+    if (n && n <= ws.small_max && n <= ws.cap) {   // small call: one launch, one workgroup per item
+        const int rate = ws.fips ? 136 : 168;
+        if (kem) launch("k_keygen_small", k_keygen_small<K, ETA1, true>, n, WAVE * SMALL_WAVES, st, n, d, z, ek, dk, ws.A, ws.prf, ws.rho, ws.r, rate);
+        else launch("k_keygen_small", k_keygen_small<K, ETA1, false>, n, WAVE * SMALL_WAVES, st, n, d, z, ek, dk, ws.A, ws.prf, ws.rho, ws.r, rate);
+        return;
+    }
     for (size_t h0 = 0; h0 < n; h0 += ws.hcap) {
         const size_t hn = min_sz(ws.hcap, n - h0);
         launch("k_hash_keygen_seed", k_hash_keygen_seed<K>, ceil_div(hn, WAVE), WAVE, st, hn, d + h0 * 32, ws.rho, ws.r);
@@ -250,6 +259,12 @@ template <int K, int ETA1, int DU, int DV>
 // r_user != nullptr: K-PKE.Encrypt alone (ml_kem.c:776-936) with the caller's randomness; no hashing, Kout unused
 inline void encaps_run(stream_t st, const ParamSet& p, size_t n, const uint8_t* ek, const uint8_t* m, uint8_t* c, uint8_t* Kout,
                        int32_t* mod_status, const Workspace& ws, const uint8_t* r_user = nullptr) {
+    if (n == 0) return;
+    if (!r_user && n <= ws.small_max && n <= ws.cap) {   // small call: one launch, one workgroup per item
+        launch("k_encaps_small", k_encaps_small<K, ETA1, DU, DV>, n, WAVE * SMALL_WAVES, st, n, ek, m, c, Kout, mod_status, ws.A, ws.prf, ws.r,
+               ws.fips ? 136 : 168);
+        return;
+    }
     SideFork fork(ws, st, r_user ? (size_t)-1 : n);   // one chunk: A-hat^T (needs rho alone) is sampled beside H(ek) and G
     if (fork.active()) launch_sample_split(fork.xof_stream(), p, n, 0, ek + 384 * K, p.ek_len, /*transpose=*/1, nullptr, 2 * K + 1, K, ws);
     for (size_t h0 = 0; h0 < n; h0 += ws.hcap) {
@@ -288,6 +303,17 @@ template <int K, int ETA1, int DU, int DV>
 inline void decaps_run(stream_t st, const ParamSet& p, size_t n, const uint8_t* dk, const uint8_t* c, uint8_t* Kout,
                        int32_t* status, bool hash_check, const Workspace& ws) {
     constexpr int CLEN = 32 * (DU * K + DV);
+    if (n && n <= ws.small_max && n <= ws.cap) {   // small call: one launch, one workgroup per item
+        const int rate = ws.fips ? 136 : 168;
+        int32_t* sts = hash_check ? status : (int32_t*)nullptr;
+#define MLKEM_DS(HC, JR) launch("k_decaps_small", k_decaps_small<K, ETA1, DU, DV, HC, JR>, n, WAVE * SMALL_WAVES, st, n, dk, c, Kout, sts, ws.A, ws.prf, ws.r, ws.m, ws.Kp, ws.Kbar, rate)
+        if (hash_check && !ws.fips) MLKEM_DS(true, 168);
+        else if (!ws.fips) MLKEM_DS(false, 168);
+        else if (hash_check) MLKEM_DS(true, 136);
+        else MLKEM_DS(false, 136);
+#undef MLKEM_DS
+        return;
+    }
     for (size_t h0 = 0; h0 < n; h0 += ws.hcap) {
         const size_t hn = min_sz(ws.hcap, n - h0);
         const uint8_t* dkh = dk + h0 * p.dk_len;

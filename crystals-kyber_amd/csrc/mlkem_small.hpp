@@ -1,0 +1,288 @@
+// mlkem_small.hpp — ONE WORKGROUP PER ITEM: ML-KEM KeyGen / Encaps / Decaps for small calls, each a single launch.
+//
+// A call of one to a few hundred items -- every call of the ml_kem.h drop-in API -- cannot fill the GPU; its time is the
+// length of its dependency chain: H(ek) (9 sequential permutations at k = 3) -> G -> PRF -> Encrypt for Encaps.  The batch path
+// spreads that chain over four kernels on two streams (lane-sliced or wave-wide sponges, sampler, arithmetic) and pays a launch
+// gap between each.  Here the item's whole operation is one workgroup of SMALL_WAVES wavefronts that run the item's
+// independent sponges SIDE BY SIDE, each on the one-sponge-per-wave Keccak of mlkem_wkeccak.hpp (3.5 us per permutation for a
+// lone wave instead of 8.8 lane-sliced), meet at workgroup barriers, and hand the sampled matrix and the PRF rows to the
+// arithmetic (the same encrypt2_body / keygen2_body / decrypt4_body the batch kernels run) through the call's scratch in HBM:
+//   k_encaps_small  stage 1: wave 0: h = H(ek), (K, r) = G(m || h)        | waves 1..: A-hat^T = SampleNTT(rho || j || i)
+//                   stage 2: all waves: PRF(r, n), n = 0..2k
+//                   stage 3: wave 0: K-PKE.Encrypt                                            (ml_kem.c:1093-1130, :776-936)
+//   k_decaps_small  stage 1: wave 0: m' = K-PKE.Decrypt, (K', r') = G(m' || h) | wave 1: Kbar = J(z || c)
+//                            wave 2: status = H(dk.ek) == dk.h ? 0 : -5        | waves 3..: A-hat^T
+//                   stage 2: PRF(r', n) ; stage 3: wave 0: c' = Encrypt, K = c == c' ? K' : Kbar   (ml_kem.c:1310-1359, :1136-1225)
+//   k_keygen_small  stage 1: wave 0: (rho, sigma) = G(d || k) ; stage 2: all waves: A-hat and the 2k PRF rows
+//                   stage 3: wave 0: K-PKE.KeyGen, then H(ek) and the dk tail                 (ml_kem.c:1034-1084, :651-769)
+// SampleNTT on a wave: the squeezed block (168 bytes in 21 SIMD lanes) goes through 176 bytes of LDS so that SIMD lane t
+// reads triple t (ml_kem.c:208-219: 3 bytes -> two 12-bit candidates); the accepted candidates of the 56 lanes are put in order
+// with two ballots and a prefix count and stored straight to the polynomial.  The triple limit and the seed-mutation retry of
+// the reference (ml_kem.c:221-242) are reproduced: template parameters QB (acceptance bound) and CAP (usable triples) exist so
+// that the CPU tier can drive this branch (tests/test_emulated_kernels.py); the product instantiates (3329, 278).
+#pragma once
+#include "mlkem_wkeccak.hpp"
+#include "mlkem_kpke2.hpp"
+#include "mlkem_kpke4.hpp"
+
+namespace mlkem {
+
+constexpr int SMALL_WAVES = 8;   // 512 threads: two waves per SIMD, i.e. the 256 VGPRs the K-PKE bodies may need (k = 4)
+
+#ifdef MLKEM_EMU
+__device__ __forceinline__ void block_barrier() { emu::block_barrier(); }
+__device__ __forceinline__ void wave_global_fence() { emu::wave_barrier(); }
+#else
+__device__ __forceinline__ void block_barrier() { __syncthreads(); }
+// a wave's own global stores (made by other lanes) before its later loads of the same bytes
+__device__ __forceinline__ void wave_global_fence() { __threadfence_block(); }
+#endif
+
+constexpr int XOF_LDS_WORDS = 44;   // 168 squeezed bytes + the dword the last triple's unaligned read touches
+
+// ------------------------------------------------------------------------------------------------
+// SampleNTT (ml_kem.c:189-245), one sponge on the calling wave: seed = rho[32] || i0 || i1 -> poly[256] (uint16, < QB)
+// ------------------------------------------------------------------------------------------------
+template <int QB = KQ, int CAP = 278>
+__device__ __forceinline__ void wk_sample_ntt(const WkLane& c, const uint8_t* rho, unsigned i0, unsigned i1, uint16_t* poly, uint32_t* sq) {
+    static_assert(CAP > 224 && CAP <= 280, "the limit falls into the fifth squeeze block");
+    const int i = wk_index();
+    const bool prim = wk_primary();
+    const unsigned l = (unsigned)lane_id();
+    uint2 seed;
+    seed.x = 0; seed.y = 0;
+    if (i >= 0 && i < 4) seed = reinterpret_cast<const uint2*>(rho)[i];
+    const unsigned bo = 3u * l, w = bo >> 2, sh = 8u * (bo & 3u);   // triple l of a block: bytes 3 l .. 3 l + 2
+    const unsigned long long below = (1ull << l) - 1ull;
+    for (;;) {
+        WkState a;
+        a.lo = seed.x; a.hi = seed.y;
+        if (i == 4) a.lo = (i0 & 0xFFu) | ((i1 & 0xFFu) << 8) | (0x1Fu << 16);   // bytes 32, 33 and the SHAKE suffix
+        if (i == 20) a.hi = 0x80000000u;                                            // pad10*1 ends at byte 167
+        unsigned cnt = 0;
+#pragma unroll 1
+        for (int blk = 0; blk < 5 && cnt < 256u; blk++) {
+            wk_permute(a, c);
+            if (prim && i < 21) { sq[2 * i] = a.lo; sq[2 * i + 1] = a.hi; }
+            wave_lds_fence();
+            uint32_t v = 0;
+            if (l < 56u) v = __builtin_amdgcn_alignbit(sq[w + 1], sq[w], sh) & 0xFFFFFFu;
+            wave_lds_fence();
+            // the fifth block: the triple that would be number CAP + 1 only trips the reference's limit (ml_kem.c:223-227)
+            const unsigned ntr = blk == 4 ? (unsigned)(CAP - 224) : 56u;
+            const unsigned d1 = v & 0xFFFu, d2 = v >> 12;
+            const bool ok1 = l < ntr && d1 < (unsigned)QB, ok2 = l < ntr && d2 < (unsigned)QB;
+            const unsigned long long m1 = __ballot(ok1), m2 = __ballot(ok2);
+            const unsigned pos1 = cnt + (unsigned)__builtin_popcountll(m1 & below) + (unsigned)__builtin_popcountll(m2 & below);
+            const unsigned pos2 = pos1 + (ok1 ? 1u : 0u);
+            if (ok1 && pos1 < 256u) poly[pos1] = (uint16_t)d1;
+            if (ok2 && pos2 < 256u) poly[pos2] = (uint16_t)d2;
+            cnt += (unsigned)__builtin_popcountll(m1) + (unsigned)__builtin_popcountll(m2);
+        }
+        if (cnt >= 256u) break;
+        i0 = (i0 + 1u) & 0xFFu;    // ml_kem.c:237-242: B[32]++, B[33]++ and start over
+        i1 = (i1 + 1u) & 0xFFu;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// PRF (ml_kem.c:496-515): SHAKE(r[32] || ctr) -> 64 eta bytes at `out`; rate 168 = SHAKE128 like the reference (F2), 136 = SHAKE256
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void wk_prf(const WkLane& c, const uint8_t* r32, unsigned ctr, unsigned eta, unsigned rate, uint8_t* out) {
+    const int i = wk_index();
+    const bool prim = wk_primary();
+    WkState a;
+    a.lo = 0; a.hi = 0;
+    if (i >= 0 && i < 4) {
+        const uint2 v = reinterpret_cast<const uint2*>(r32)[i];
+        a.lo = v.x; a.hi = v.y;
+    }
+    if (i == 4) a.lo = (ctr & 0xFFu) | (0x1Fu << 8);
+    const int nq = (int)(rate / 8u), want = (int)(8u * eta);   // qwords per block, qwords wanted (16 or 24)
+    if (i == nq - 1) a.hi ^= 0x80000000u;
+    wk_permute(a, c);
+    uint2 o;
+    o.x = a.lo; o.y = a.hi;
+    if (prim && i < (want < nq ? want : nq)) reinterpret_cast<uint2*>(out)[i] = o;
+    if (want > nq) {                                            // eta = 3: the head of the second block
+        wk_permute(a, c);
+        o.x = a.lo; o.y = a.hi;
+        if (prim && i < want - nq) reinterpret_cast<uint2*>(out)[nq + i] = o;
+    }
+}
+
+// H(msg) for a message of `len` bytes (multiple of 8) at `msg`: digest in Keccak lanes 0..3 of `a`
+__device__ __forceinline__ void wk_H(WkState& a, const WkLane& c, const uint8_t* msg, unsigned len) {
+    wk_absorb<136, 0x06>(a, c, msg, len, msg, len);
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_encaps_small — ML-KEM.Encaps_internal (ml_kem.c:1093-1130), one workgroup per item
+//   A, prf, r_ws: the call's scratch (K*K*256 uint16, (2K+1)*PS bytes, 32 bytes per item)
+// ------------------------------------------------------------------------------------------------
+template <int K, int ETA1, int DU, int DV>
+__global__ void __launch_bounds__(WAVE * SMALL_WAVES)
+k_encaps_small(size_t n, const uint8_t* __restrict__ ek, const uint8_t* __restrict__ m, uint8_t* __restrict__ c, uint8_t* __restrict__ Kout,
+               int32_t* __restrict__ mod_status, uint16_t* A, uint8_t* prf, uint8_t* r_ws, int prf_rate) {
+    __shared__ K2Lds<K + 1> xl;
+    __shared__ uint32_t sq[SMALL_WAVES][XOF_LDS_WORDS];
+    constexpr unsigned EK = 384 * K + 32, PS = (ETA1 == 3) ? 192 : 128, CLEN = 32 * (DU * K + DV);
+    const int wv = wave_id();
+    const size_t item = blockIdx.x;
+    if (item >= n) return;
+    const uint8_t* my_ek = ek + item * EK;
+    uint16_t* my_A = A + item * (size_t)(K * K * 256);
+    uint8_t* my_prf = prf + item * (size_t)((2 * K + 1) * PS);
+    uint8_t* my_r = r_ws + item * 32;
+    WkLane cst;
+    wk_lane_init(cst);
+    if (wv == 0) {                                   // h = H(ek) ; (K, r) = G(m || h)
+        const int i = wk_index();
+        WkState a;
+        wk_H(a, cst, my_ek, EK);
+        uint2 mv;
+        mv.x = 0; mv.y = 0;
+        if (i >= 0 && i < 4) mv = reinterpret_cast<const uint2*>(m + item * 32)[i];
+        wk_G_of_x_and_digest(a, cst, mv);
+        uint2 o;
+        o.x = a.lo; o.y = a.hi;
+        if (wk_primary() && i < 4) reinterpret_cast<uint2*>(Kout + item * 32)[i] = o;
+        else if (wk_primary() && i < 8) reinterpret_cast<uint2*>(my_r)[i - 4] = o;
+    } else {                                         // A-hat^T[a][b] = SampleNTT(rho || a || b)   (ml_kem.c:817-823)
+        for (int s = wv - 1; s < K * K; s += SMALL_WAVES - 1)
+            wk_sample_ntt(cst, my_ek + 384 * K, (unsigned)(s / K), (unsigned)(s % K), my_A + s * 256, sq[wv]);
+    }
+    block_barrier();
+    for (int j = wv; j < 2 * K + 1; j += SMALL_WAVES)
+        wk_prf(cst, my_r, (unsigned)j, j < K ? (unsigned)ETA1 : 2u, (unsigned)prf_rate, my_prf + j * PS);
+    block_barrier();
+    if (wv == 0)
+        encrypt2_body<K, ETA1, DU, DV, false>(xl.xch, 0, 1, my_ek, (size_t)EK, m + item * 32, my_A, my_prf, c + item * CLEN, nullptr, nullptr, nullptr,
+                                              nullptr, mod_status ? mod_status + item : nullptr, (size_t)(K * K * 256));
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_decaps_small — KEM_Decaps / Decaps_internal (ml_kem.c:1310-1359, :1136-1225), one workgroup per item
+// ------------------------------------------------------------------------------------------------
+template <int K, int ETA1, int DU, int DV, bool HASH_CHECK, int JRATE>
+__global__ void __launch_bounds__(WAVE * SMALL_WAVES)
+k_decaps_small(size_t n, const uint8_t* __restrict__ dk, const uint8_t* __restrict__ c, uint8_t* __restrict__ Kout, int32_t* __restrict__ status,
+               uint16_t* A, uint8_t* prf, uint8_t* r_ws, uint8_t* m_ws, uint8_t* Kp_ws, uint8_t* Kbar_ws, int prf_rate) {
+    __shared__ K2Lds<K + 1> xl;
+    __shared__ uint32_t sq[SMALL_WAVES][XOF_LDS_WORDS];
+    constexpr unsigned EK = 384 * K + 32, DK = 768 * K + 96, PS = (ETA1 == 3) ? 192 : 128, CLEN = 32 * (DU * K + DV);
+    constexpr int FIRST_XOF = HASH_CHECK ? 3 : 2;    // waves 0 .. FIRST_XOF - 1 run the serial roles
+    const int wv = wave_id();
+    const size_t item = blockIdx.x;
+    if (item >= n) return;
+    const uint8_t* my_dk = dk + item * DK;
+    const uint8_t* my_c = c + item * CLEN;
+    uint16_t* my_A = A + item * (size_t)(K * K * 256);
+    uint8_t* my_prf = prf + item * (size_t)((2 * K + 1) * PS);
+    uint8_t *my_r = r_ws + item * 32, *my_m = m_ws + item * 32, *my_Kp = Kp_ws + item * 32, *my_Kbar = Kbar_ws + item * 32;
+    WkLane cst;
+    wk_lane_init(cst);
+    const int i = wk_index();
+    const bool prim = wk_primary();
+    if (wv == 0) {                                   // m' = K-PKE.Decrypt(dk_pke, c) ; (K', r') = G(m' || h)
+        decrypt4_body<K, DU, DV>(0, 1, my_dk, (size_t)DK, my_c, my_m);
+        wave_global_fence();
+        uint2 v;
+        v.x = 0; v.y = 0;
+        if (i >= 0 && i < 4) v = reinterpret_cast<const uint2*>(my_m)[i];
+        else if (i >= 4 && i < 8) v = reinterpret_cast<const uint2*>(my_dk + 768 * K + 32)[i - 4];
+        WkState a;
+        a.lo = v.x; a.hi = v.y;
+        if (i == 8) { a.lo = 0x06u; a.hi = 0x80000000u; }
+        wk_permute(a, cst);
+        uint2 o;
+        o.x = a.lo; o.y = a.hi;
+        if (prim && i < 4) reinterpret_cast<uint2*>(my_Kp)[i] = o;
+        else if (prim && i < 8) reinterpret_cast<uint2*>(my_r)[i - 4] = o;
+        if (!HASH_CHECK && lane_id() == 0 && status) status[item] = 0;
+    } else if (wv == 1) {                            // Kbar = J(z || c)
+        WkState a;
+        wk_absorb<JRATE, 0x1F>(a, cst, my_dk + 768 * K + 64, 32, my_c, 32 + CLEN);
+        uint2 o;
+        o.x = a.lo; o.y = a.hi;
+        if (prim && i < 4) reinterpret_cast<uint2*>(my_Kbar)[i] = o;
+    } else if (HASH_CHECK && wv == 2) {              // KEM_Decaps' check of the stored H(ek)
+        WkState a;
+        wk_H(a, cst, my_dk + 384 * K, EK);
+        uint2 h;
+        h.x = 0; h.y = 0;
+        if (prim && i < 4) h = reinterpret_cast<const uint2*>(my_dk + 768 * K + 32)[i];
+        const bool differ = prim && i < 4 && (h.x != a.lo || h.y != a.hi);
+        const bool bad = __ballot(differ) != 0;
+        if (lane_id() == 0 && status) status[item] = bad ? -5 : 0;
+    } else {                                         // A-hat^T of the re-encryption (rho sits in dk.ek)
+        for (int s = wv - FIRST_XOF; s < K * K; s += SMALL_WAVES - FIRST_XOF)
+            wk_sample_ntt(cst, my_dk + 768 * K, (unsigned)(s / K), (unsigned)(s % K), my_A + s * 256, sq[wv]);
+    }
+    block_barrier();
+    for (int j = wv; j < 2 * K + 1; j += SMALL_WAVES)
+        wk_prf(cst, my_r, (unsigned)j, j < K ? (unsigned)ETA1 : 2u, (unsigned)prf_rate, my_prf + j * PS);
+    block_barrier();
+    if (wv == 0)
+        encrypt2_body<K, ETA1, DU, DV, true>(xl.xch, 0, 1, my_dk + 384 * K, (size_t)DK, my_m, my_A, my_prf, nullptr, my_c, my_Kp, my_Kbar,
+                                             Kout + item * 32, nullptr, (size_t)(K * K * 256));
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_keygen_small — ML-KEM.KeyGen_internal (ml_kem.c:1034-1084) ; KEM_DK = false: K-PKE.KeyGen alone (dk = the 384k bytes of s-hat)
+// ------------------------------------------------------------------------------------------------
+template <int K, int ETA1, bool KEM_DK>
+__global__ void __launch_bounds__(WAVE * SMALL_WAVES)
+k_keygen_small(size_t n, const uint8_t* __restrict__ d, const uint8_t* __restrict__ z, uint8_t* ek, uint8_t* dk, uint16_t* A, uint8_t* prf,
+               uint8_t* rho_ws, uint8_t* sigma_ws, int prf_rate) {
+    __shared__ K2Lds<K> xl;
+    __shared__ uint32_t sq[SMALL_WAVES][XOF_LDS_WORDS];
+    constexpr unsigned EK = 384 * K + 32, DK = KEM_DK ? 768 * K + 96 : 384 * K, PS = (ETA1 == 3) ? 192 : 128;
+    const int wv = wave_id();
+    const size_t item = blockIdx.x;
+    if (item >= n) return;
+    uint8_t *my_ek = ek + item * EK, *my_dk = dk + item * DK;
+    uint16_t* my_A = A + item * (size_t)(K * K * 256);
+    uint8_t* my_prf = prf + item * (size_t)(2 * K * PS);
+    uint8_t *my_rho = rho_ws + item * 32, *my_sigma = sigma_ws + item * 32;
+    WkLane cst;
+    wk_lane_init(cst);
+    const int i = wk_index();
+    const bool prim = wk_primary();
+    if (wv == 0) {                                   // (rho, sigma) = G(d || k)   (ml_kem.c:674-681)
+        WkState a;
+        a.lo = 0; a.hi = 0;
+        if (i >= 0 && i < 4) {
+            const uint2 v = reinterpret_cast<const uint2*>(d + item * 32)[i];
+            a.lo = v.x; a.hi = v.y;
+        }
+        if (i == 4) a.lo = (unsigned)K | (0x06u << 8);
+        if (i == 8) a.hi = 0x80000000u;
+        wk_permute(a, cst);
+        uint2 o;
+        o.x = a.lo; o.y = a.hi;
+        if (prim && i < 4) reinterpret_cast<uint2*>(my_rho)[i] = o;
+        else if (prim && i < 8) reinterpret_cast<uint2*>(my_sigma)[i - 4] = o;
+    }
+    block_barrier();
+    // A-hat[a][b] = SampleNTT(rho || b || a) (ml_kem.c:686-693) and the 2k PRF rows (s: n = 0..k-1, e: n = k..2k-1, all eta1)
+    for (int j = wv; j < K * K + 2 * K; j += SMALL_WAVES) {
+        if (j < K * K) wk_sample_ntt(cst, my_rho, (unsigned)(j % K), (unsigned)(j / K), my_A + j * 256, sq[wv]);
+        else wk_prf(cst, my_sigma, (unsigned)(j - K * K), (unsigned)ETA1, (unsigned)prf_rate, my_prf + (j - K * K) * PS);
+    }
+    block_barrier();
+    if (wv == 0) {
+        keygen2_body<K, ETA1, KEM_DK>(xl.xch, 0, 1, my_A, my_prf, my_rho, my_ek, my_dk);
+        if constexpr (KEM_DK) {                      // dk tail: H(ek) || z   (ml_kem.c:1065-1077)
+            wave_global_fence();
+            WkState a;
+            wk_H(a, cst, my_ek, EK);
+            uint2 o;
+            o.x = a.lo; o.y = a.hi;
+            if (i >= 4 && i < 8) o = reinterpret_cast<const uint2*>(z + item * 32)[i - 4];
+            if (prim && i < 8) reinterpret_cast<uint2*>(my_dk + 768 * K + 32)[i] = o;
+        }
+    }
+}
+
+}   // namespace mlkem

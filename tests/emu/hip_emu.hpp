@@ -37,7 +37,9 @@ struct WaveCtx {
     uint64_t slot[64];
 };
 static thread_local WaveCtx* wave = nullptr;
+static thread_local pthread_barrier_t* block_bar = nullptr;
 inline void wave_barrier() { pthread_barrier_wait(&wave->bar); }
+inline void block_barrier() { pthread_barrier_wait(block_bar); }   // __syncthreads(): every thread of the workgroup must arrive
 
 template <class F>
 inline void launch(unsigned grid, unsigned block, F body) {
@@ -48,15 +50,19 @@ inline void launch(unsigned grid, unsigned block, F body) {
             unsigned lanes = block - 64 * w < 64 ? block - 64 * w : 64;
             pthread_barrier_init(&ctx[w].bar, nullptr, lanes);
         }
+        pthread_barrier_t bbar;
+        pthread_barrier_init(&bbar, nullptr, block);
         std::vector<std::thread> th;
         th.reserve(block);
         for (unsigned t = 0; t < block; t++)
             th.emplace_back([&, t, b] {
                 threadIdx.x = t; blockIdx.x = b; gridDim.x = grid; blockDim.x = block;
                 wave = &ctx[t / 64];
+                block_bar = &bbar;
                 body();
             });
         for (auto& x : th) x.join();
+        pthread_barrier_destroy(&bbar);
         for (unsigned w = 0; w < nwaves; w++) pthread_barrier_destroy(&ctx[w].bar);
     }
 }

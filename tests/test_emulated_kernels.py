@@ -509,3 +509,43 @@ def test_emu_one_sponge_per_wave_hash_kernels(emu, oracle, pset, fips):
         emu.emu_wide_hash(C.c_size_t(0))
         emu.emu_conformance(0)
         oracle.set_conformance(False)
+
+
+@pytest.mark.parametrize("pset,fips", ((512, 0), (768, 0), (1024, 1)))
+def test_emu_one_workgroup_per_item_kernels(emu, oracle, pset, fips):
+    """mlkem_small.hpp (calls of at most `small_max` items): KeyGen, Encaps and Decaps each as ONE launch, a workgroup of eight
+    waves per item -- wave-level SampleNTT (ballot + prefix-count compaction), PRF, H / G / J and the K-PKE bodies behind
+    workgroup barriers.  Two items: an untouched and a tampered ciphertext, then a corrupted stored H(ek); bit for bit against
+    the oracle (reference mode for 512 / 768, FIPS 203 mode -- PRF and J on SHAKE256 -- for 1024)."""
+    n = 2
+    ekl, dkl, cl = SIZES[pset]
+    emu.emu_conformance(fips)
+    emu.emu_small(C.c_size_t(16))
+    try:
+        d, z, m = seeds("sm-d", n, pset), seeds("sm-z", n, pset), seeds("sm-m", n, pset)
+        oracle.set_conformance(bool(fips))
+        ek, dk = oracle.keygen(pset, d, z)
+        ek_e, dk_e = np.zeros((n, ekl), np.uint8), np.zeros((n, dkl), np.uint8)
+        assert emu.emu_keygen(pset, C.c_size_t(n), p8(d), p8(z), p8(ek_e), p8(dk_e)) == 0
+        assert (ek_e == ek).all() and (dk_e == dk).all()
+        c, K = np.zeros((n, cl), np.uint8), np.zeros((n, 32), np.uint8)
+        st = np.ones(n, np.int32)
+        assert emu.emu_encaps(pset, C.c_size_t(n), p8(ek), p8(m), p8(c), p8(K), st.ctypes.data_as(C.POINTER(C.c_int32)) if fips else None) == 0
+        c_o, K_o = oracle.encaps(pset, ek, m)
+        assert (c == c_o).all() and (K == K_o).all()
+        if fips:
+            assert (st == 0).all()
+        cb, dkb = c.copy(), dk.copy()
+        cb[1, 40] ^= 4                                     # item 1: implicit rejection
+        Kd, st = np.zeros((n, 32), np.uint8), np.ones(n, np.int32)
+        assert emu.emu_decaps(pset, C.c_size_t(n), p8(dkb), p8(cb), p8(Kd), st.ctypes.data_as(C.POINTER(C.c_int32)), 1) == 0
+        Kd_o, st_o = oracle.decaps(pset, dkb, cb)
+        assert (st == 0).all() and (st_o == 0).all() and (Kd == Kd_o).all()
+        assert (Kd[0] == K[0]).all() and (Kd[1] != K[1]).any()
+        dkb[0, dkl - 40] ^= 1                              # item 0: stored H(ek) corrupted -> status -5, key = Decaps_internal's
+        assert emu.emu_decaps(pset, C.c_size_t(1), p8(dkb), p8(cb), p8(Kd), st.ctypes.data_as(C.POINTER(C.c_int32)), 1) == 0
+        assert st[0] == -5 and (Kd[0] == oracle.decaps_internal(pset, dkb[0], cb[0])).all()
+    finally:
+        emu.emu_small(C.c_size_t(0))
+        emu.emu_conformance(0)
+        oracle.set_conformance(False)
