@@ -9,8 +9,8 @@ HDRS  := $(wildcard $(CSRC)/*.hpp) include/mlkem_batch.h include/mlkem_compat.h
 
 all: $(PKG)/libmlkem_amd.so $(PKG)/libml_kem.so
 
-$(PKG)/libmlkem_amd.so: $(CSRC)/mlkem_capi.hip $(HDRS)
-	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -fPIC -shared -o $@ $(CSRC)/mlkem_capi.hip
+$(PKG)/libmlkem_amd.so: $(CSRC)/mlkem_capi.hip $(CSRC)/exports.map $(HDRS)
+	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -fvisibility=hidden -fPIC -shared -Wl,--version-script=$(CSRC)/exports.map -o $@ $(CSRC)/mlkem_capi.hip
 
 $(PKG)/libml_kem.so: $(CSRC)/ml_kem_shim.c $(PKG)/libmlkem_amd.so $(HDRS)
 	gcc -O2 -fPIC -shared -o $@ $(CSRC)/ml_kem_shim.c -L$(PKG) -lmlkem_amd -Wl,-rpath,'$$ORIGIN'

@@ -298,10 +298,48 @@ def probe_medians(cp):
     return (cp["sclk_mhz"]["median"], cp["socket_w"]["median"]) if cp else (None, None)
 
 
-def per_gpu_entry(rank, device, units, steps, own_s, ok, cp):
+def per_gpu_entry(rank, device, units, steps, own_s, ok, cp, solo=None):
     clk, pw = probe_medians(cp)
-    return {"rank": rank, "device": device.index, "name": torch.cuda.get_device_name(device), "value": units * steps / own_s,
-            "ms_per_step": 1e3 * own_s / steps, "correct": bool(ok), "sclk_mhz": clk, "socket_w": pw}
+    e = {"rank": rank, "device": device.index, "name": torch.cuda.get_device_name(device), "value": units * steps / own_s,
+         "ms_per_step": 1e3 * own_s / steps, "correct": bool(ok), "sclk_mhz": clk, "socket_w": pw}
+    if solo is not None:
+        e["solo_value"] = solo
+    return e
+
+
+SOLO_STEPS = 5
+
+
+def solo_anchor(step, sync, rank, world, units):
+    """The N = 1 anchor INSIDE the N > 1 job: before the group-timed region every rank in turn runs SOLO_STEPS steps of the same
+    workload ALONE on its GPU while the others idle at a barrier.  aggregate / sum(solo values) is then a scaling efficiency
+    between runs of one job on one set of devices, instead of against an N = 1 run on another box (box-to-box spread: +-4 %).
+    Returns this rank's solo units/s (None when the job has one rank)."""
+    if world <= 1:
+        return None
+    mine = None
+    for r in range(world):
+        barrier(world)
+        if r == rank:
+            sync()
+            t0 = time.perf_counter()
+            for _ in range(SOLO_STEPS):
+                step()
+            sync()
+            mine = units * SOLO_STEPS / (time.perf_counter() - t0)
+    barrier(world)
+    return mine
+
+
+def scaling_anchor(value, per_gpu):
+    """aggregate vs the in-job solo runs (see solo_anchor); None when a rank has no solo value."""
+    if not per_gpu or any(g.get("solo_value") is None for g in per_gpu) or len(per_gpu) < 2:
+        return None
+    total = sum(g["solo_value"] for g in per_gpu)
+    return {"solo_steps": SOLO_STEPS, "sum_solo_value": total, "efficiency": value / total,
+            "per_gpu_efficiency": [g["value"] / g["solo_value"] for g in per_gpu],
+            "note": "solo_value = the same step run by that rank alone while the other ranks wait at a barrier, in this job, "
+                    "before the group-timed region; efficiency = aggregate value / sum of solo values"}
 
 
 def run_kem(args, pset, rank, world, device):
@@ -333,6 +371,7 @@ def run_kem(args, pset, rank, world, device):
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize(device)
+    solo = solo_anchor(step, lambda: torch.cuda.synchronize(device), rank, world, n)
     barrier(world)
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -355,7 +394,7 @@ def run_kem(args, pset, rank, world, device):
     same = (Kt == K).all(dim=1)
     ok = ok and not bool(same[idx].any()) and int(same.sum()) == n - idx.numel() and int(stt.abs().max()) == 0
 
-    extra = {"per_gpu": per_gpu_entry(rank, device, n, args.steps, own, ok, clock_power), "clock_power": clock_power}
+    extra = {"per_gpu": per_gpu_entry(rank, device, n, args.steps, own, ok, clock_power, solo), "clock_power": clock_power}
     if rank == 0:
         # per-kernel HIP-event timing of TIMING_PASSES more passes (not part of `value`); totals are per pass
         with pkg.kernel_timing() as kt:
@@ -399,6 +438,19 @@ def run_kem_inproc(args, pset, members):
     for _ in range(args.warmup):
         step()
     mm.sync()
+    # the N = 1 anchor inside the job (solo_anchor's rule): each member in turn runs alone, the others get empty shards
+    solos = [None] * members
+    if members > 1:
+        for r in range(members):
+            only = lambda ts: [t if i == r else t[:0] for i, t in enumerate(ts)]   # noqa: E731
+            a = [only(x) for x in (ek, m, c, K, dk, K2, st)]
+            mm.sync()
+            t0 = time.perf_counter()
+            for _ in range(SOLO_STEPS):
+                mm.encaps_dev(a[0], a[1], c=a[2], K=a[3])
+                mm.decaps_dev(a[4], a[2], K=a[5], status=a[6])
+            mm.sync()
+            solos[r] = n * SOLO_STEPS / (time.perf_counter() - t0)
     ext = mm.streams()
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(members)]
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(members)]
@@ -418,7 +470,7 @@ def run_kem_inproc(args, pset, members):
     ok_all, per_gpu = True, []
     for r in range(members):
         ok = bool(torch.equal(K[r], K2[r])) and int(st[r].abs().max()) == 0
-        per_gpu.append(per_gpu_entry(r, devs[r], n, args.steps, own[r], ok, cps[devices[r]]))
+        per_gpu.append(per_gpu_entry(r, devs[r], n, args.steps, own[r], ok, cps[devices[r]], solos[r]))
         ok_all = ok_all and ok
     ct = [t.clone() for t in c]
     idx = [torch.arange(0, n, 1024, device=dv) for dv in devs]
@@ -459,6 +511,7 @@ def run_ntt(args, rank, world, device):
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize(device)
+    solo = solo_anchor(step, lambda: torch.cuda.synchronize(device), rank, world, n)
     barrier(world)
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -470,7 +523,7 @@ def run_ntt(args, rank, world, device):
     clock_power = clock_power_probe(step, device)
     barrier(world)
     ok = bool(torch.equal(f, f2)) and int(fh.min()) >= 0 and int(fh.max()) < 3329
-    extra = {"per_gpu": per_gpu_entry(rank, device, n, args.steps, own, ok, clock_power), "clock_power": clock_power}
+    extra = {"per_gpu": per_gpu_entry(rank, device, n, args.steps, own, ok, clock_power, solo), "clock_power": clock_power}
     if rank == 0:
         with pkg.kernel_timing() as kt:
             for _ in range(TIMING_PASSES):
@@ -680,6 +733,9 @@ def main():
             "data": "synthetic", "config": {"workload": wl % args.batch, "batch_per_gpu": args.batch, "parallelism": par,
                                             "chunk_items": extra.get("chunk_items")},
             "correct": ok, "per_gpu": per_gpu, "roofline": e["roofline"], "kernels": e["kernels"]}
+    anchor = scaling_anchor(e["value"], per_gpu)
+    if anchor:
+        line["scaling_anchor"] = anchor
     if "cpu_baseline" in extra:
         line["cpu_baseline"] = extra["cpu_baseline"]
     if also:
@@ -707,6 +763,9 @@ def main_inproc(args):
             "data": "synthetic", "config": {"workload": wl % args.batch, "batch_per_gpu": args.batch, "parallelism": par,
                                             "chunk_items": extra.get("chunk_items"), "member_devices": extra["devices"]},
             "correct": ok, "per_gpu": extra["per_gpu_all"], "roofline": e["roofline"], "kernels": e["kernels"]}
+    anchor = scaling_anchor(e["value"], extra["per_gpu_all"])
+    if anchor:
+        line["scaling_anchor"] = anchor
     print(json.dumps(line))
     if not ok:
         sys.exit(3)

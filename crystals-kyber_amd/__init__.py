@@ -40,7 +40,7 @@ ABI_SYMBOLS = (
     "mlkem_selftest_count", "mlkem_selftest", "mlkem_host_release", "mlkem_host_register", "mlkem_host_unregister",
     "mlkem_multi_create", "mlkem_multi_destroy", "mlkem_multi_members", "mlkem_multi_device", "mlkem_shard_range",
     "mlkem_keygen_multi", "mlkem_encaps_multi", "mlkem_decaps_multi",
-    "mlkem_keygen_multi_dev", "mlkem_encaps_multi_dev", "mlkem_decaps_multi_dev", "mlkem_multi_sync", "mlkem_multi_stream",
+    "mlkem_keygen_multi_dev", "mlkem_encaps_multi_dev", "mlkem_decaps_multi_dev", "mlkem_multi_sync", "mlkem_multi_stream", "mlkem_stream_last_staged",
     "mlkem_vector_multiply_dev", "mlkem_poly_add_dev", "mlkem_poly_sub_dev",
 )
 SHIM_SYMBOLS = ("init", "KEM_KeyGen", "KEM_Encaps", "KEM_Decaps", "ml_errno", "sha3_b", "sha3_h", "sha3_s", "h2b", "b2h",

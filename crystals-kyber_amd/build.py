@@ -16,7 +16,8 @@ SHIM = os.path.join(HERE, "libml_kem.so")
 # -fno-slp-vectorize: left to itself the compiler packs pairs of the kernels' scalar fp32 operations into v_pk_fma_f32 /
 # v_pk_add_f32, which issue at half rate on gfx950 (no gain) and cost moves + registers to form the operand pairs: the K-PKE
 # kernels are 3-5 % faster without it (profiles/r03_kpke_experiments.txt).
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize"]
+# -fvisibility=hidden: the library exports the C-ABI of include/mlkem_batch.h (MLKEM_API) and nothing else.
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-fvisibility=hidden"]
 
 
 def _newer(target, sources):
@@ -44,7 +45,7 @@ def build(force=False):
     srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(root, "include", "mlkem_batch.h"),
                                                                  os.path.join(root, "include", "mlkem_compat.h")]
     if force or not _newer(LIB, srcs):
-        _run([hipcc_path(), *HIPCC_FLAGS, "-fPIC", "-shared", "-o", LIB,
+        _run([hipcc_path(), *HIPCC_FLAGS, "-fPIC", "-shared", "-Wl,--version-script=" + os.path.join(CSRC, "exports.map"), "-o", LIB,
               os.path.join(CSRC, "mlkem_capi.hip")])
     if force or not _newer(SHIM, srcs + [LIB]):
         _run(["gcc", "-O2", "-fPIC", "-shared", "-o", SHIM, os.path.join(CSRC, "ml_kem_shim.c"),

@@ -190,7 +190,8 @@ __device__ __forceinline__ unsigned poly_sub1(unsigned a, unsigned b) {
     return (a < b ? (unsigned)KQ - (b - a) : a - b) & 0xFFFu;
 }
 template <bool SUB>
-__global__ void __launch_bounds__(256) k_poly_addsub(size_t n, const uint16_t* __restrict__ a, const uint16_t* __restrict__ b, uint16_t* __restrict__ out) {
+// (no __restrict__: out may be a or b -- every element is read by the thread that then writes it)
+__global__ void __launch_bounds__(256) k_poly_addsub(size_t n, const uint16_t* a, const uint16_t* b, uint16_t* out) {
     const size_t groups = n / 8, stride = (size_t)gridDim.x * blockDim.x;
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     auto f = [](unsigned x, unsigned y) { return SUB ? poly_sub1(x, y) : poly_add1(x, y); };
@@ -274,7 +275,7 @@ __device__ __forceinline__ unsigned decompress_any(unsigned y, int d) {
     return ((t >> d) + ((t & ((1u << d) - 1u)) >= (1u << (d - 1)) ? 1u : 0u)) & 0xFFFu;
 }
 template <bool DECOMPRESS>
-__global__ void __launch_bounds__(256) k_compress_values(size_t n, int d, const uint16_t* __restrict__ in, uint16_t* __restrict__ out) {
+__global__ void __launch_bounds__(256) k_compress_values(size_t n, int d, const uint16_t* in, uint16_t* out) {   // out may be in
     const size_t groups = n / 8, stride = (size_t)gridDim.x * blockDim.x;
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     auto f = [d](unsigned v) { return DECOMPRESS ? decompress_any(v, d) : compress_any(v, d); };

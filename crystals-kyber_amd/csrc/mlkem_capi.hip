@@ -393,7 +393,7 @@ int mlkem_poly_sub_dev(mlkem_ctx* ctx, size_t n_values, const uint16_t* u, const
 }
 int mlkem_sample_ntt_dev(mlkem_ctx* ctx, size_t n, const uint8_t* seeds34, uint16_t* a, void* stream) {
     if (!ctx_ok(ctx) || (n && (!seeds34 || !a)) || !aligned16(a)) return MLKEM_ERR_ARG;
-    if (n) sample_ntt_launch(static_cast<hipStream_t>(stream), n, seeds34, a);
+    if (n) sample_ntt_launch(static_cast<hipStream_t>(stream), n, seeds34, a, ctx->ws.wide_max);
     HIP_TRY(hipGetLastError());
     return MLKEM_OK;
 }
@@ -587,12 +587,18 @@ bool host_pinned(const void* p, size_t bytes) {
     hipDeviceptr_t base = nullptr;
     size_t size = 0;
     if (hipMemGetAddressRange(&base, &size, const_cast<void*>(p)) == hipSuccess) {
+        // the range decides only when it is a host range around p: for hipHostRegister'ed memory the runtime may report no
+        // base, a device-side alias or a size of its own; then the two end bytes decide
         const uint8_t* lo = static_cast<const uint8_t*>(base);
-        return b >= lo && b + bytes <= lo + size;
+        if (lo && size && b >= lo && b < lo + size) return b + bytes <= lo + size;
+        return true;
     }
     (void)hipGetLastError();       // no range for this kind of pointer: the two end bytes decide
     return true;
 }
+// bit j set: span j of the calling thread's last streaming call went through the engine's pinned staging buffer (pageable or
+// partly registered caller memory); -1 before the first call.  Lets a test see a silent demotion of a registered buffer.
+thread_local int t_last_staged = -1;
 
 struct StageBuf {
     void* dev = nullptr;
@@ -697,6 +703,8 @@ int stream_op(StreamEngine& e, size_t n, size_t chunk, const std::vector<Span>& 
     const int nsets = nchunks < (size_t)NSETS ? (int)nchunks : NSETS;
     std::vector<char> staged(spans.size());
     for (size_t j = 0; j < spans.size(); j++) staged[j] = !host_pinned(spans[j].in ? spans[j].in : spans[j].out, n * spans[j].bytes);
+    t_last_staged = 0;
+    for (size_t j = 0; j < spans.size() && j < 31; j++) t_last_staged |= staged[j] ? (1 << j) : 0;
     int rc = engine_prepare(e, dev, chunk, spans, staged, nsets);
     auto drain = [&](BufSet& s) -> int {   // wait for the set's D2H copies and hand staged outputs to the caller
         if (!s.pending) return MLKEM_OK;
@@ -894,6 +902,8 @@ int mlkem_decaps_stream(int set, size_t n, const uint8_t* dk, const uint8_t* c, 
     return kem_stream_current(2, set, n, dk, c, K, status, chunk_items);
 }
 
+int mlkem_stream_last_staged(void) { return t_last_staged; }
+
 // pins caller memory so that the streaming calls hand it to the DMA engines directly (no staging copy)
 int mlkem_host_register(void* p, size_t bytes) {
     if (!p || !bytes) return MLKEM_ERR_ARG;
@@ -1056,6 +1066,7 @@ int mlkem_encaps_random(int set, size_t n, const uint8_t* ek, unsigned ek_len, u
 // One persistent host thread per member: started on the member's first host-resident call, bound to the member's device
 // once, fed one job at a time through a mutex + condition variable, joined by mlkem_multi_destroy.  (A std::thread per
 // call cost a thread creation + hipSetDevice per member and call.)
+namespace {
 struct MemberWorker {
     std::mutex mu;
     std::condition_variable cv;
@@ -1104,6 +1115,7 @@ struct MemberWorker {
         th.join();
     }
 };
+}   // namespace
 
 struct mlkem_multi {
     struct Member {

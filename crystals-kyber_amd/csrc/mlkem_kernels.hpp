@@ -643,25 +643,40 @@ __device__ __forceinline__ void ring_flush(const int16_t* ring, uint16_t* A, siz
     if (has) flushed += 64;
 }
 
+// The reference squeezes 280 triples and gives up when the triple that would be number 279 comes up (ml_kem.c:221-229): the
+// usable triples are 0 .. SAMPLE_CAP - 1 = 277, i.e. four full blocks of 56 and the first 54 of the fifth; a polynomial still
+// short after them restarts from the mutated seed (ml_kem.c:237-242).  The acceptance bound QB and the cap CAP are template
+// parameters of every sampler so that the CPU tier can run these branches (a fifth block is otherwise reached with
+// probability ~ e^-40 per sponge, the retry with ~ e^-220): tests/test_emulated_kernels.py instantiates the wave emulator with
+// lower values; the product instantiates (KQ, SAMPLE_CAP) only.
+constexpr int SAMPLE_CAP = 278;
+// triples of the fifth block's group G (four triples per three dwords) that may be used under cap CAP
+constexpr int sample_nt5(int cap, int g) { return cap - 224 - 4 * g >= 4 ? 4 : (cap - 224 - 4 * g <= 0 ? 0 : cap - 224 - 4 * g); }
+
 // one candidate of SampleNTT (ml_kem.c:211-219)
 #define MLKEM_CAND(d)                                                      \
     {                                                                      \
-        const bool ok = ((d) < (unsigned)KQ) && (cnt < 256);               \
+        const bool ok = ((d) < (unsigned)QB) && (cnt < 256);               \
         if (ok) myring[cnt & (RING - 1)] = (int16_t)(d);                   \
         cnt += ok ? 1 : 0;                                                 \
     }
-// four 3-byte groups out of three state dwords; TRIPLES limits how many of the four are consumed
+// four 3-byte groups out of three state dwords; NT limits how many of the four are consumed
 #define MLKEM_GROUP4(W0, NT)                                                                      \
     {                                                                                             \
         const uint32_t w0 = keccak_word<W0>(s), w1 = keccak_word<W0 + 1>(s), w2 = keccak_word<W0 + 2>(s); \
         const uint32_t v0 = w0 & 0xFFFFFFu, v1 = (w0 >> 24) | ((w1 & 0xFFFFu) << 8);              \
         const uint32_t v2 = (w1 >> 16) | ((w2 & 0xFFu) << 16), v3 = w2 >> 8;                      \
-        MLKEM_CAND(v0 & 0xFFFu) MLKEM_CAND(v0 >> 12)                                              \
-        MLKEM_CAND(v1 & 0xFFFu) MLKEM_CAND(v1 >> 12)                                              \
+        if (NT > 0) { MLKEM_CAND(v0 & 0xFFFu) MLKEM_CAND(v0 >> 12) }                              \
+        if (NT > 1) { MLKEM_CAND(v1 & 0xFFFu) MLKEM_CAND(v1 >> 12) }                              \
         if (NT > 2) { MLKEM_CAND(v2 & 0xFFFu) MLKEM_CAND(v2 >> 12) }                              \
         if (NT > 3) { MLKEM_CAND(v3 & 0xFFFu) MLKEM_CAND(v3 >> 12) }                              \
     }
+// group G of a block: all four triples, except in the fifth block (blk == 4) where the cap may cut it short
+#define MLKEM_GROUP4_CAP(W0, G)                                                                   \
+    if constexpr (sample_nt5(CAP, G) == 4) { MLKEM_GROUP4(W0, 4) }                                \
+    else { if (blk == 4) MLKEM_GROUP4(W0, sample_nt5(CAP, G)) else MLKEM_GROUP4(W0, 4) }
 
+template <int QB = KQ, int CAP = SAMPLE_CAP>
 __global__ void __launch_bounds__(WAVE) k_sample(SampleArgs a) {
     __shared__ __attribute__((aligned(16))) int16_t ring[WAVE * RING_STRIDE];
     const int l = lane_id();
@@ -711,16 +726,15 @@ __global__ void __launch_bounds__(WAVE) k_sample(SampleArgs a) {
             }
             keccak_f1600(s);
             // first half of the block: triples 0..27  (dwords 0..20)
-            MLKEM_GROUP4(0, 4) MLKEM_GROUP4(3, 4) MLKEM_GROUP4(6, 4) MLKEM_GROUP4(9, 4)
-            MLKEM_GROUP4(12, 4) MLKEM_GROUP4(15, 4) MLKEM_GROUP4(18, 4)
+            MLKEM_GROUP4_CAP(0, 0) MLKEM_GROUP4_CAP(3, 1) MLKEM_GROUP4_CAP(6, 2) MLKEM_GROUP4_CAP(9, 3)
+            MLKEM_GROUP4_CAP(12, 4) MLKEM_GROUP4_CAP(15, 5) MLKEM_GROUP4_CAP(18, 6)
             wave_lds_fence();
             ring_flush(ring, a.A, g, valid, cnt, flushed);
             wave_lds_fence();
             // second half: triples 28..55 (dwords 21..41); in the 5th block the reference never uses
             // triples 278, 279 (ml_kem.c:223-227: the 279th triple only trips the iteration limit)
-            MLKEM_GROUP4(21, 4) MLKEM_GROUP4(24, 4) MLKEM_GROUP4(27, 4) MLKEM_GROUP4(30, 4)
-            MLKEM_GROUP4(33, 4) MLKEM_GROUP4(36, 4)
-            if (blk == 4) MLKEM_GROUP4(39, 2) else MLKEM_GROUP4(39, 4)
+            MLKEM_GROUP4_CAP(21, 7) MLKEM_GROUP4_CAP(24, 8) MLKEM_GROUP4_CAP(27, 9) MLKEM_GROUP4_CAP(30, 10)
+            MLKEM_GROUP4_CAP(33, 11) MLKEM_GROUP4_CAP(36, 12) MLKEM_GROUP4_CAP(39, 13)
             wave_lds_fence();
             ring_flush(ring, a.A, g, valid, cnt, flushed);
             wave_lds_fence();

@@ -171,6 +171,9 @@ inline size_t min_sz(size_t a, size_t b) { return a < b ? a : b; }
 // (ml_kem.c:189-245, :496-515)
 // n_xof_items / n_prf_items: items whose matrix / PRF rows are produced (equal except for shared-key batches, where the
 // matrix is sampled once and the PRF rows per item)
+// QB, CAP: acceptance bound and triple cap of SampleNTT (mlkem_kernels.hpp: the product uses the defaults; the CPU tier also
+// instantiates lower values to run the fifth squeeze block and the seed-mutation retry)
+template <int QB = KQ, int CAP = SAMPLE_CAP>
 inline void launch_sample_split(stream_t st, const ParamSet& p, size_t n_xof_items, size_t n_prf_items, const uint8_t* rho, size_t rho_stride,
                                 int transpose, const uint8_t* r, int prf_per_item, int n_eta1, const Workspace& ws) {
     SampleArgs a{};
@@ -191,11 +194,11 @@ inline void launch_sample_split(stream_t st, const ParamSet& p, size_t n_xof_ite
         // small call: the general sampler finishes every sponge itself (a wave runs a fourth permutation when one of its lanes
         // needs it) -- one launch instead of three, 0.045 instead of 0.08 ms on the call's critical path; at full batches the
         // three-block kernel + hand-over is 13 % cheaper (mlkem_sampler.hpp)
-        launch("k_sample_direct", k_sample, grid, WAVE, st, a);
+        launch("k_sample_direct", k_sample<QB, CAP>, grid, WAVE, st, a);
         return;
     }
     if (a.n_xof) zero_u32x2(st, ws.leftover);   // the counters belong to the stream that samples the matrix
-    launch("k_sample_main", k_sample_main, grid, WAVE, st, a);
+    launch("k_sample_main", k_sample_main<QB>, grid, WAVE, st, a);
     if (a.n_xof == 0) return;
     // leftovers: expected 0.8 % of the sponges; the grids cover 1/16 of them and stride over the rest if ever needed.
     // First the sponges handed over with their state (one more permutation each), then the restart list (normally empty).
@@ -204,14 +207,15 @@ inline void launch_sample_split(stream_t st, const ParamSet& p, size_t n_xof_ite
     t.n_prf = 0;
     t.xof_blocks = (unsigned)(ceil_div(a.n_xof, WAVE * 16) + 1);
     if (a.resume_cap) {
-        launch("k_sample_tail", k_sample_resume, (size_t)t.xof_blocks, WAVE, st, t);
+        launch("k_sample_tail", k_sample_resume<QB, CAP>, (size_t)t.xof_blocks, WAVE, st, t);
         t.xof_blocks = (unsigned)(ceil_div(a.n_xof, WAVE * 256) + 1);
     }
-    launch("k_sample_restart", k_sample, (size_t)t.xof_blocks, WAVE, st, t);
+    launch("k_sample_restart", k_sample<QB, CAP>, (size_t)t.xof_blocks, WAVE, st, t);
 }
+template <int QB = KQ, int CAP = SAMPLE_CAP>
 inline void launch_sample(stream_t st, const ParamSet& p, size_t n, const uint8_t* rho, size_t rho_stride, int transpose,
                           const uint8_t* r, int prf_per_item, int n_eta1, const Workspace& ws) {
-    launch_sample_split(st, p, n, n, rho, rho_stride, transpose, r, prf_per_item, n_eta1, ws);
+    launch_sample_split<QB, CAP>(st, p, n, n, rho, rho_stride, transpose, r, prf_per_item, n_eta1, ws);
 }
 
 // K-PKE.Encrypt launch: two items per wave (mlkem_kpke2.hpp)
@@ -560,17 +564,23 @@ inline int compress_values_launch(stream_t st, bool decompress, int d, size_t n,
     return 0;
 }
 // stand-alone SampleNTT over explicit 34-byte seeds: the general kernel in direct mode
-inline void sample_ntt_launch(stream_t st, size_t n, const uint8_t* seeds34, uint16_t* out) {
+// (calls of at most `wave_max` seeds: one sponge per wave, mlkem_small.hpp -- the ml_kem.h shim's SampleNTT is a call of one)
+template <int QB = KQ, int CAP = SAMPLE_CAP>
+inline void sample_ntt_launch(stream_t st, size_t n, const uint8_t* seeds34, uint16_t* out, size_t wave_max = 0) {
+    if (n <= wave_max) {
+        launch("k_sample_xof", k_sample_ntt_w<QB, CAP>, n, WAVE, st, n, seeds34, out);
+        return;
+    }
     SampleArgs a{};
     a.n_xof = n; a.rho = seeds34; a.rho_stride = 34; a.K = 0; a.A = out;
     a.xof_blocks = (unsigned)ceil_div(n, WAVE);
-    launch("k_sample_xof", k_sample, (size_t)a.xof_blocks, WAVE, st, a);
+    launch("k_sample_xof", k_sample<QB, CAP>, (size_t)a.xof_blocks, WAVE, st, a);
 }
 inline int prf_launch(stream_t st, int eta, size_t n, const uint8_t* in33, uint8_t* out) {
     if (eta != 2 && eta != 3) return -1;
     SampleArgs a{};
     a.n_prf = n; a.r = in33; a.per_item = 0; a.eta1 = eta; a.prf = out; a.prf_stride = 64u * (unsigned)eta;
-    launch("k_sample_prf", k_sample, ceil_div(n, WAVE), WAVE, st, a);
+    launch("k_sample_prf", k_sample<>, ceil_div(n, WAVE), WAVE, st, a);
     return 0;
 }
 inline int hash_launch(stream_t st, int kind, size_t n, const uint8_t* msg, unsigned len, size_t stride, uint8_t* out) {

@@ -22,8 +22,8 @@ namespace mlkem {
 // are ever staged: 56 candidates between flush points).
 constexpr int LIN_STRIDE = 144;   // bytes per lane: 9 x 16, rows 16-byte aligned, 36-dword skew
 #ifdef MLKEM_EMU
-#define MLKEM_LIN_ACCEPT(lds0, pos, d) { if ((d) < (uint32_t)KQ) { *reinterpret_cast<int16_t*>((lds0) + (pos)) = (int16_t)(d); (pos) += 2u; } }
-#define MLKEM_LIN_ACCEPT_LIM(lds0, pos, d, lim) { if ((d) < (uint32_t)KQ && (pos) < (lim)) { *reinterpret_cast<int16_t*>((lds0) + (pos)) = (int16_t)(d); (pos) += 2u; } }
+#define MLKEM_LIN_ACCEPT(lds0, pos, d) { if ((d) < (uint32_t)QB) { *reinterpret_cast<int16_t*>((lds0) + (pos)) = (int16_t)(d); (pos) += 2u; } }
+#define MLKEM_LIN_ACCEPT_LIM(lds0, pos, d, lim) { if ((d) < (uint32_t)QB && (pos) < (lim)) { *reinterpret_cast<int16_t*>((lds0) + (pos)) = (int16_t)(d); (pos) += 2u; } }
 #else
 // all 64 lanes are active in the XOF role (sponges beyond n_xof are clamped duplicates), so EXEC is restored to -1
 #define MLKEM_LIN_ACCEPT(lds0, pos, d)                                              \
@@ -84,7 +84,11 @@ __device__ __forceinline__ void lin_flush(char* buf, uint32_t pos0, uint32_t& po
     flushed += 32u * n32;
 }
 
+template <int QB = KQ>
 __global__ void __launch_bounds__(WAVE, 4) k_sample_main(SampleArgs a) {   // 9 KB of LDS per wave: 4 waves per SIMD
+#ifndef MLKEM_EMU
+    static_assert(QB == 0xd01, "the acceptance bound is a literal of the inline assembly (MLKEM_LIN_ACCEPT)");
+#endif
     static_assert(WAVE * LIN_STRIDE >= 32 * 33 * 4, "the PRF role stages 32 rows x 33 dwords in the same buffer");
     __shared__ __attribute__((aligned(16))) char stage[WAVE * LIN_STRIDE];
     const int l = lane_id();
@@ -217,6 +221,7 @@ __global__ void __launch_bounds__(WAVE, 4) k_sample_main(SampleArgs a) {   // 9 
 // 2-byte stores per sponge).  One permutation instead of the four a restart from the seed costs; the pass is latency-bound
 // (one wave per CU), so this is wall time.  A sponge still short after block five follows the reference's retry
 // (ml_kem.c:221-242: 279-triple limit, seed mutation): it goes to the restart list for k_sample.
+template <int QB = KQ, int CAP = SAMPLE_CAP>
 __global__ void __launch_bounds__(WAVE) k_sample_resume(SampleArgs a) {
     const int l = lane_id();
     const size_t limit = (size_t)(a.leftover[1] < a.resume_cap ? a.leftover[1] : a.resume_cap);
@@ -235,18 +240,20 @@ __global__ void __launch_bounds__(WAVE) k_sample_resume(SampleArgs a) {
         MLKEM_LD(40) MLKEM_LD(41) MLKEM_LD(42) MLKEM_LD(43) MLKEM_LD(44) MLKEM_LD(45) MLKEM_LD(46) MLKEM_LD(47) MLKEM_LD(48) MLKEM_LD(49)
 #undef MLKEM_LD
         uint16_t* poly = a.A + g * 256;
-#define MLKEM_RC(d) { const uint32_t dd = (d); if (dd < (uint32_t)KQ && cnt < 256u) { poly[cnt] = (uint16_t)dd; cnt++; } }
+#define MLKEM_RC(d) { const uint32_t dd = (d); if (dd < (uint32_t)QB && cnt < 256u) { poly[cnt] = (uint16_t)dd; cnt++; } }
+// group G of the block; in the fifth block the reference never uses the triples from the cap on (ml_kem.c:223-227: with the
+// product's CAP = 278 that is triples 278, 279 -- the 279th only trips the limit)
+#define MLKEM_RG(W0, G)                                                                                         \
+            if constexpr (sample_nt5(CAP, G) == 4) { MLKEM_LG(MLKEM_RC, W0, 0, 4) }                             \
+            else { if (blk == 4) { MLKEM_LG(MLKEM_RC, W0, 0, sample_nt5(CAP, G)) } else { MLKEM_LG(MLKEM_RC, W0, 0, 4) } }
 #pragma unroll 1
         for (int blk = 3; blk < 5; blk++) {
             keccak_f1600(s);
-            MLKEM_LG(MLKEM_RC, 0, 0, 4) MLKEM_LG(MLKEM_RC, 3, 0, 4) MLKEM_LG(MLKEM_RC, 6, 0, 4) MLKEM_LG(MLKEM_RC, 9, 0, 4)
-            MLKEM_LG(MLKEM_RC, 12, 0, 4) MLKEM_LG(MLKEM_RC, 15, 0, 4) MLKEM_LG(MLKEM_RC, 18, 0, 4) MLKEM_LG(MLKEM_RC, 21, 0, 4)
-            MLKEM_LG(MLKEM_RC, 24, 0, 4) MLKEM_LG(MLKEM_RC, 27, 0, 4) MLKEM_LG(MLKEM_RC, 30, 0, 4) MLKEM_LG(MLKEM_RC, 33, 0, 4)
-            MLKEM_LG(MLKEM_RC, 36, 0, 4)
-            // in the fifth block the reference never uses triples 278, 279 (ml_kem.c:223-227: the 279th only trips the limit)
-            if (blk == 4) { MLKEM_LG(MLKEM_RC, 39, 0, 2) } else { MLKEM_LG(MLKEM_RC, 39, 0, 4) }
+            MLKEM_RG(0, 0) MLKEM_RG(3, 1) MLKEM_RG(6, 2) MLKEM_RG(9, 3) MLKEM_RG(12, 4) MLKEM_RG(15, 5) MLKEM_RG(18, 6)
+            MLKEM_RG(21, 7) MLKEM_RG(24, 8) MLKEM_RG(27, 9) MLKEM_RG(30, 10) MLKEM_RG(33, 11) MLKEM_RG(36, 12) MLKEM_RG(39, 13)
             if (__ballot(cnt < 256u) == 0) break;
         }
+#undef MLKEM_RG
 #undef MLKEM_RC
         if (cnt < 256u) {   // valid lanes only (the others start at 256): restart from the mutated seed, as the reference does
             const uint32_t j = atomicAdd(&a.leftover[0], 1u);

@@ -19,7 +19,7 @@
 // reads triple t (ml_kem.c:208-219: 3 bytes -> two 12-bit candidates); the accepted candidates of the 56 lanes are put in order
 // with two ballots and a prefix count and stored straight to the polynomial.  The triple limit and the seed-mutation retry of
 // the reference (ml_kem.c:221-242) are reproduced: template parameters QB (acceptance bound) and CAP (usable triples) exist so
-// that the CPU tier can drive this branch (tests/test_emulated_kernels.py); the product instantiates (3329, 278).
+// that the CPU tier can drive this branch (tests/test_emulated_kernels.py); the product instantiates (KQ, SAMPLE_CAP) only.
 #pragma once
 #include "mlkem_wkeccak.hpp"
 #include "mlkem_kpke2.hpp"
@@ -43,15 +43,14 @@ constexpr int XOF_LDS_WORDS = 44;   // 168 squeezed bytes + the dword the last t
 // ------------------------------------------------------------------------------------------------
 // SampleNTT (ml_kem.c:189-245), one sponge on the calling wave: seed = rho[32] || i0 || i1 -> poly[256] (uint16, < QB)
 // ------------------------------------------------------------------------------------------------
-template <int QB = KQ, int CAP = 278>
-__device__ __forceinline__ void wk_sample_ntt(const WkLane& c, const uint8_t* rho, unsigned i0, unsigned i1, uint16_t* poly, uint32_t* sq) {
+// `seed`: bytes [8 i, 8 i + 8) of rho in the SIMD lanes of Keccak index i < 4 (copies included), anything elsewhere
+template <int QB = KQ, int CAP = SAMPLE_CAP>
+__device__ __forceinline__ void wk_sample_ntt_seed(const WkLane& c, uint2 seed, unsigned i0, unsigned i1, uint16_t* poly, uint32_t* sq) {
     static_assert(CAP > 224 && CAP <= 280, "the limit falls into the fifth squeeze block");
     const int i = wk_index();
     const bool prim = wk_primary();
     const unsigned l = (unsigned)lane_id();
-    uint2 seed;
-    seed.x = 0; seed.y = 0;
-    if (i >= 0 && i < 4) seed = reinterpret_cast<const uint2*>(rho)[i];
+    if (!(i >= 0 && i < 4)) { seed.x = 0; seed.y = 0; }
     const unsigned bo = 3u * l, w = bo >> 2, sh = 8u * (bo & 3u);   // triple l of a block: bytes 3 l .. 3 l + 2
     const unsigned long long below = (1ull << l) - 1ull;
     for (;;) {
@@ -83,6 +82,35 @@ __device__ __forceinline__ void wk_sample_ntt(const WkLane& c, const uint8_t* rh
         i0 = (i0 + 1u) & 0xFFu;    // ml_kem.c:237-242: B[32]++, B[33]++ and start over
         i1 = (i1 + 1u) & 0xFFu;
     }
+}
+
+// rho: 32 bytes, 8-byte aligned
+template <int QB = KQ, int CAP = SAMPLE_CAP>
+__device__ __forceinline__ void wk_sample_ntt(const WkLane& c, const uint8_t* rho, unsigned i0, unsigned i1, uint16_t* poly, uint32_t* sq) {
+    const int i = wk_index();
+    uint2 seed;
+    seed.x = 0; seed.y = 0;
+    if (i >= 0 && i < 4) seed = reinterpret_cast<const uint2*>(rho)[i];
+    wk_sample_ntt_seed<QB, CAP>(c, seed, i0, i1, poly, sq);
+}
+// k_sample_ntt_w — stand-alone SampleNTT over explicit 34-byte seeds (any alignment), one sponge per wave
+template <int QB = KQ, int CAP = SAMPLE_CAP>
+__global__ void __launch_bounds__(WAVE) k_sample_ntt_w(size_t n, const uint8_t* __restrict__ seeds34, uint16_t* __restrict__ out) {
+    __shared__ uint32_t sq[XOF_LDS_WORDS];
+    const size_t g = blockIdx.x;
+    if (g >= n) return;
+    const uint8_t* sp = seeds34 + g * 34;
+    const int i = wk_index();
+    uint2 seed;
+    seed.x = 0; seed.y = 0;
+    if (i >= 0 && i < 4) {
+        const uint8_t* b = sp + 8 * i;
+        seed.x = (uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16) | ((uint32_t)b[3] << 24);
+        seed.y = (uint32_t)b[4] | ((uint32_t)b[5] << 8) | ((uint32_t)b[6] << 16) | ((uint32_t)b[7] << 24);
+    }
+    WkLane c;
+    wk_lane_init(c);
+    wk_sample_ntt_seed<QB, CAP>(c, seed, sp[32], sp[33], out + g * 256, sq);
 }
 
 // ------------------------------------------------------------------------------------------------

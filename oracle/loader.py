@@ -193,6 +193,16 @@ class Oracle:
         self.lib.orc_sample_ntt(_p8(B), _p16(a))
         return a
 
+    def sample_ntt_bounded(self, B, bound, limit):
+        """Test-only generalisation of SampleNTT (acceptance bound, triple limit; the reference is (3329, 279)).
+        Returns (polynomial, retries, the 34 seed bytes of the attempt that succeeded)."""
+        B = _u8(B, 34)
+        a = np.zeros(256, np.uint16)
+        Bo = np.zeros(34, np.uint8)
+        self.lib.orc_sample_ntt_bounded.restype = C.c_int
+        r = self.lib.orc_sample_ntt_bounded(_p8(B), _p16(a), C.c_uint(bound), C.c_uint(limit), _p8(Bo))
+        return a, r, Bo
+
     def sample_cbd(self, B, eta):
         B = _u8(B, 64 * eta)
         f = np.zeros(256, np.uint16)

@@ -227,7 +227,13 @@ void orc_byte_decode(const uint8_t *B, unsigned d, uint16_t F[256]) { /* ml_kem.
 /* ------------------------------------------------------------------------------------------
  * Sampling — ml_kem.c:189-275
  * ---------------------------------------------------------------------------------------- */
-int orc_sample_ntt(const uint8_t B_in[34], uint16_t a[256]) {
+/* SampleNTT with the acceptance bound and the triple limit as parameters.  The reference is (q, 279): candidates < q are
+ * accepted (ml_kem.c:211-219) and the loop gives up once `limit` triples have been consumed (ml_kem.c:223-227:
+ * k >= 280*24 - 24), then mutates B[32], B[33] and starts over (ml_kem.c:237-242).  Other values exist for the tests only:
+ * with the real bound a sponge needs a fifth block with probability ~ e^-40 and the retry never happens, so the CPU tier
+ * runs the kernels' templates with a lower bound / limit against this function (tests/test_emulated_kernels.py).
+ * B_out (may be NULL) receives the 34 seed bytes of the attempt that succeeded.  Returns the number of retries. */
+int orc_sample_ntt_bounded(const uint8_t B_in[34], uint16_t a[256], unsigned bound, unsigned limit, uint8_t B_out[34]) {
     uint8_t B[34], S[840];
     int retries = 0;
     memcpy(B, B_in, 34);
@@ -238,17 +244,21 @@ int orc_sample_ntt(const uint8_t B_in[34], uint16_t a[256]) {
         while (j < 256) { /* ml_kem.c:203-230 */
             unsigned c0 = S[3 * t], c1 = S[3 * t + 1], c2 = S[3 * t + 2];
             unsigned d1 = c0 + 256 * (c1 % 16), d2 = c1 / 16 + 16 * c2;
-            if (d1 < ORC_Q) a[j++] = (uint16_t)d1;
-            if (d2 < ORC_Q && j < 256) a[j++] = (uint16_t)d2;
+            if (d1 < bound) a[j++] = (uint16_t)d1;
+            if (d2 < bound && j < 256) a[j++] = (uint16_t)d2;
             t++;
-            if (t >= 279) { exhausted = 1; break; } /* ml_kem.c:223-227: k >= 280*24 - 24 */
+            if (t >= limit) { exhausted = 1; break; }
         }
-        if (!exhausted) return retries;
+        if (!exhausted) {
+            if (B_out) memcpy(B_out, B, 34);
+            return retries;
+        }
         B[32] = (uint8_t)(B[32] + 1); /* ml_kem.c:237-242 */
         B[33] = (uint8_t)(B[33] + 1);
         retries++;
     }
 }
+int orc_sample_ntt(const uint8_t B_in[34], uint16_t a[256]) { return orc_sample_ntt_bounded(B_in, a, ORC_Q, 279, NULL); }
 
 void orc_sample_cbd(const uint8_t *B, unsigned eta, uint16_t f[256]) { /* ml_kem.c:253-275 */
     for (unsigned i = 0; i < 256; i++) {

@@ -65,6 +65,8 @@ void orc_byte_encode(const uint16_t F[256], unsigned d, uint8_t *B);   /* ml_kem
 void orc_byte_decode(const uint8_t *B, unsigned d, uint16_t F[256]);   /* ml_kem.c:153 */
 /* ml_kem.c:189; returns the number of seed-mutation retries taken (0 in practice). */
 int orc_sample_ntt(const uint8_t B[34], uint16_t a[256]);
+/* test-only generalisation: acceptance bound and triple limit as parameters ((q, 279) = the reference) */
+int orc_sample_ntt_bounded(const uint8_t B[34], uint16_t a[256], unsigned bound, unsigned limit, uint8_t B_out[34]);
 void orc_sample_cbd(const uint8_t *B, unsigned eta, uint16_t f[256]);  /* ml_kem.c:253 */
 void orc_ntt(const uint16_t f[256], uint16_t fh[256]);                 /* ml_kem.c:287 */
 void orc_intt(const uint16_t fh[256], uint16_t f[256]);                /* ml_kem.c:336 */

@@ -54,6 +54,23 @@ static long compress_f_mismatches() {
     return bad;
 }
 
+template <int QB, int CAP>
+static int sample_matrix_bounded(int k, size_t n, const uint8_t* rho, int transpose, uint16_t* A_out, int direct) {
+    Workspace ws = make_ws(n);
+    ws.wide_max = direct ? n : 0;
+    ParamSet p;
+    param_set(k == 2 ? 512 : k == 3 ? 768 : 1024, p);
+    uint8_t* r = (uint8_t*)xalloc(n * 32);
+    for (size_t i = 0; i < n * 32; i++) r[i] = (uint8_t)i;
+    ws.leftover[0] = ws.leftover[1] = 0;
+    launch_sample<QB, CAP>(nullptr, p, n, rho, 32, transpose, r, 2 * k + 1, k, ws);
+    memcpy(A_out, ws.A, n * (size_t)(k * k) * 512);
+    int left = (int)ws.leftover[1] | ((int)ws.leftover[0] << 16);
+    free(r);
+    free_ws(ws);
+    return left;
+}
+
 extern "C" {
 void emu_config(size_t cap, size_t hcap) { g_cap = cap; g_hcap = hcap; }
 void emu_conformance(int fips) { g_fips = fips != 0; }
@@ -138,6 +155,29 @@ int emu_sample_matrix(int k, size_t n, const uint8_t* rho, int transpose, uint16
     free(r);
     free_ws(ws);
     return left;
+}
+// ---- SampleNTT with a LOWERED acceptance bound / triple cap (test-only instantiations of the product's templates): the fourth
+// and fifth squeeze block, the cap inside the fifth block and the seed-mutation retry (ml_kem.c:221-242) run for a large
+// share of the sponges.  variant 0 = the product's (3329, 278); 1 = (1900, 278); 2 = (2100, 250).
+//   emu_sample_matrix_bounded : the batch path (k_sample_main -> k_sample_resume -> k_sample restart list; or k_sample direct
+//                               when `direct`), returns leftover counters like emu_sample_matrix
+//   emu_sample_ntt_bounded    : stand-alone seeds; wave = 0: lane-sliced k_sample, 1: one sponge per wave (k_sample_ntt_w)
+int emu_sample_matrix_bounded(int variant, int k, size_t n, const uint8_t* rho, int transpose, uint16_t* A_out, int direct) {
+    switch (variant) {
+    case 0: return sample_matrix_bounded<KQ, SAMPLE_CAP>(k, n, rho, transpose, A_out, direct);
+    case 1: return sample_matrix_bounded<1900, 278>(k, n, rho, transpose, A_out, direct);
+    case 2: return sample_matrix_bounded<2100, 250>(k, n, rho, transpose, A_out, direct);
+    default: return -1;
+    }
+}
+int emu_sample_ntt_bounded(int variant, int wave, size_t n, const uint8_t* seeds, uint16_t* out) {
+    const size_t wm = wave ? n : 0;
+    switch (variant) {
+    case 0: sample_ntt_launch<KQ, SAMPLE_CAP>(nullptr, n, seeds, out, wm); return 0;
+    case 1: sample_ntt_launch<1900, 278>(nullptr, n, seeds, out, wm); return 0;
+    case 2: sample_ntt_launch<2100, 250>(nullptr, n, seeds, out, wm); return 0;
+    default: return -1;
+    }
 }
 // Exhaustive check of the product's 3-FMA constant-multiplier modular product (mlkem_fntt.hpp: fmulmod_shoup) over every
 // twiddle the NTT uses (+/- the 128 zetas, 128^-1) and every integer |b| <= 10082: result must be congruent to

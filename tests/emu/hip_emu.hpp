@@ -34,8 +34,10 @@ struct alignas(16) float4 { float x, y, z, w; };
 namespace emu {
 struct WaveCtx {
     pthread_barrier_t bar;
-    uint64_t slot[64];
+    uint64_t slot[2][64];   // two exchange buffers used alternately: ONE barrier per cross-lane operation (a lane can run at
+                            // most one operation ahead of the slowest lane, and then writes the other buffer)
 };
+static thread_local unsigned xphase = 0;   // every lane of a wave executes the same sequence of cross-lane operations
 static thread_local WaveCtx* wave = nullptr;
 static thread_local pthread_barrier_t* block_bar = nullptr;
 inline void wave_barrier() { pthread_barrier_wait(&wave->bar); }
@@ -59,6 +61,7 @@ inline void launch(unsigned grid, unsigned block, F body) {
                 threadIdx.x = t; blockIdx.x = b; gridDim.x = grid; blockDim.x = block;
                 wave = &ctx[t / 64];
                 block_bar = &bbar;
+                xphase = 0;
                 body();
             });
         for (auto& x : th) x.join();
@@ -89,20 +92,19 @@ inline int __mul24(int a, int b) {
 inline unsigned __umul24(unsigned a, unsigned b) { return (unsigned)((uint64_t)(a & 0xFFFFFFu) * (b & 0xFFFFFFu)); }
 inline unsigned long long __ballot(int pred) {
     const int l = threadIdx.x & 63;
-    emu::wave->slot[l] = pred ? 1 : 0;
+    uint64_t* slot = emu::wave->slot[emu::xphase++ & 1];
+    slot[l] = pred ? 1 : 0;
     emu::wave_barrier();
     unsigned long long m = 0;
-    for (int i = 0; i < 64; i++) m |= (unsigned long long)(emu::wave->slot[i] & 1) << i;
-    emu::wave_barrier();
+    for (int i = 0; i < 64; i++) m |= (unsigned long long)(slot[i] & 1) << i;
     return m;
 }
 inline int __shfl(int v, int src) {
     const int l = threadIdx.x & 63;
-    emu::wave->slot[l] = (uint64_t)(uint32_t)v;
+    uint64_t* slot = emu::wave->slot[emu::xphase++ & 1];
+    slot[l] = (uint64_t)(uint32_t)v;
     emu::wave_barrier();
-    int r = (int)(uint32_t)emu::wave->slot[src & 63];
-    emu::wave_barrier();
-    return r;
+    return (int)(uint32_t)slot[src & 63];
 }
 inline int __shfl_xor(int v, int mask) { return __shfl(v, (int)((threadIdx.x & 63) ^ (unsigned)mask)); }
 inline uint32_t atomicOr(uint32_t* p, uint32_t v) { return __atomic_fetch_or(p, v, __ATOMIC_RELAXED); }

@@ -25,6 +25,19 @@ def test_batch_header_symbols_exported(pkg):
         assert hasattr(lib, name), name
 
 
+def test_library_exports_the_c_abi_and_nothing_else(pkg):
+    """libmlkem_amd.so is built with -fvisibility=hidden + csrc/exports.map: every defined dynamic symbol is an entry point
+    of include/mlkem_batch.h -- no template instantiations, kernel handles, worker classes or libstdc++ weak symbols that a
+    host program's same-named symbol could interpose."""
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", pkg.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    names = [ln.split()[-1] for ln in out.splitlines() if ln.strip()]
+    assert names, "no dynamic symbols?"
+    stray = [n for n in names if not n.startswith("mlkem_")]
+    assert stray == [], stray
+    assert set(names) == set(pkg.ABI_SYMBOLS), set(names) ^ set(pkg.ABI_SYMBOLS)
+
+
 def test_shim_symbols_exported(pkg):
     lib = C.CDLL(pkg.SHIM_PATH)
     for name in pkg.SHIM_SYMBOLS:

@@ -70,8 +70,23 @@ def _worker(rank, world, port, n, out_dir, use_engine):
     dv = torch.device("cuda", 0) if use_engine else torch.device("cpu")
     assert bench.all_ranks_ok(True, dv) is True
     assert bench.all_ranks_ok(rank != world - 1, dv) is False
-    per = bench.gather_per_gpu({"rank": rank, "value": 10.0 * (rank + 1)})
+    # the in-job N = 1 anchor: every rank runs SOLO_STEPS steps alone, in rank order, the others waiting at a barrier;
+    # the step appends to a file shared by the ranks, so an overlap of two ranks' solo phases would interleave their marks
+    log = os.path.join(out_dir, "solo.log")
+    def solo_step():
+        with open(log, "a") as f:
+            f.write("%d\n" % rank)
+    solo = bench.solo_anchor(solo_step, lambda: None, rank, world, 1000)
+    assert solo is not None and solo > 0
+    bench.barrier(world)
+    marks = open(log).read().split()
+    assert marks == [str(r) for r in range(world) for _ in range(bench.SOLO_STEPS)], marks
+    per = bench.gather_per_gpu({"rank": rank, "value": 10.0 * (rank + 1), "solo_value": 20.0 * (rank + 1)})
     assert [p["rank"] for p in per] == list(range(world)) and per[-1]["value"] == 10.0 * world
+    if rank == 0:
+        anc = bench.scaling_anchor(sum(p["value"] for p in per), per)
+        assert abs(anc["efficiency"] - 0.5) < 1e-12 and anc["per_gpu_efficiency"] == [0.5] * world and anc["solo_steps"] == bench.SOLO_STEPS
+        assert bench.scaling_anchor(1.0, [{"value": 1.0}]) is None and bench.solo_anchor(solo_step, lambda: None, 0, 1, 1) is None
     # gather per-item digests on rank 0 (test-only collective; the product's data path has none)
     gathered = [None] * world
     dist.all_gather_object(gathered, (lo, hi, _digests(c, K).tobytes()))

@@ -549,3 +549,81 @@ def test_emu_one_workgroup_per_item_kernels(emu, oracle, pset, fips):
         emu.emu_small(C.c_size_t(0))
         emu.emu_conformance(0)
         oracle.set_conformance(False)
+
+
+@pytest.mark.parametrize("variant,bound,cap", ((1, 1900, 278), (2, 2100, 250)))
+def test_emu_sampler_fifth_block_cap_and_seed_mutation_retry(emu, oracle, variant, bound, cap):
+    """The branches of SampleNTT that real SHAKE output never reaches (ml_kem.c:221-242: a fifth squeeze block needs < 256
+    accepted candidates out of 448, probability ~ e^-40; the 279-triple limit and the B[32]++, B[33]++ retry ~ e^-220).  The
+    product's sampler templates are instantiated with a LOWER acceptance bound and triple cap so that about half of the sponges
+    exhaust their triples: every sponge then runs a fourth and a fifth block, the cap inside the fifth, and a large share the
+    retry -- some twice or more.  All four forms against the oracle's parameterised restatement (orc_sample_ntt_bounded; its
+    (3329, 279) instance is the oracle every other test uses), ~1500 sponges per variant:
+      * batch path: k_sample_main (three blocks) -> k_sample_resume (blocks four, five, cap) -> restart list -> k_sample
+        (list mode, the retry), with a large and a small resume capacity;
+      * k_sample in direct mode (calls of <= 2048 items);
+      * stand-alone seeds, lane-sliced (k_sample) and one sponge per wave (k_sample_ntt_w = the sampler of mlkem_small.hpp).
+    Parity with the reference ON THIS BRANCH rests on reading ml_kem.c:221-242 (oracle and kernels were written from it);
+    no reference run can reach it."""
+    limit = cap + 1                                           # the reference counts the triple that trips the limit
+    k, n = 3, 40
+    rho = seeds("cap-rho%d" % variant, n, 31)
+    want = np.zeros((n, k * k, 256), np.uint16)
+    retries = []
+    for i in range(n):
+        for a in range(k):
+            for b in range(k):
+                seed = np.concatenate([rho[i], [a, b]]).astype(np.uint8)
+                want[i, a * k + b], r, Bo = oracle.sample_ntt_bounded(seed, bound, limit)
+                assert Bo[32] == (a + r) & 0xFF and Bo[33] == (b + r) & 0xFF and (Bo[:32] == rho[i]).all()
+                retries.append(r)
+    retries = np.array(retries)
+    assert (retries >= 1).sum() >= 60 and (retries >= 2).sum() >= 10, np.bincount(retries)
+    assert want.max() < bound
+    emu.emu_config(C.c_size_t(0), C.c_size_t(0))
+    for resume_cap, direct in ((512, 0), (16, 0), (64, 1)):
+        emu.emu_resume_cap(resume_cap)
+        A = np.zeros((n, k * k, 256), np.uint16)
+        left = emu.emu_sample_matrix_bounded(variant, k, C.c_size_t(n), p8(rho), 1, p16(A), direct)
+        emu.emu_resume_cap(64)
+        assert left >= 0
+        if not direct:
+            handed, restarted = left & 0xFFFF, left >> 16
+            assert handed == n * k * k                        # after three blocks nobody has 256 coefficients under this bound
+            assert restarted >= max(0, handed - resume_cap) + (retries >= 1).sum() * (resume_cap >= handed)
+        assert (A == want).all(), (resume_cap, direct, np.argwhere((A != want).any(axis=2))[:5])
+    # stand-alone seeds, arbitrary bytes 32 and 33 (the mutation wraps modulo 256)
+    ns = 440
+    s34 = np.concatenate([seeds("cap-s%d" % variant, ns, 7), seeds("cap-t%d" % variant, ns, 8)[:, :2]], axis=1).astype(np.uint8)
+    s34[:8, 32] = 255
+    s34[8:16, 33] = 254
+    ws = [oracle.sample_ntt_bounded(s34[i], bound, limit) for i in range(ns)]
+    wpoly = np.stack([w[0] for w in ws])
+    assert sum(w[1] >= 1 for w in ws) >= 100
+    out = np.zeros((ns, 256), np.uint16)
+    assert emu.emu_sample_ntt_bounded(variant, 0, C.c_size_t(ns), p8(s34), p16(out)) == 0
+    assert (out == wpoly).all()
+    # one sponge per wave (64 host threads per sponge, a barrier per cross-lane operation: slow): 14 seeds chosen by their
+    # retry count -- none, one, two or more
+    r_of = np.array([w[1] for w in ws])
+    pick = np.concatenate([np.nonzero(r_of == 0)[0][:5], np.nonzero(r_of == 1)[0][:5], np.nonzero(r_of >= 2)[0][:4]])
+    assert len(pick) == 14
+    sw = np.ascontiguousarray(s34[pick])
+    out = np.zeros((len(pick), 256), np.uint16)
+    assert emu.emu_sample_ntt_bounded(variant, 1, C.c_size_t(len(pick)), p8(sw), p16(out)) == 0
+    assert (out == wpoly[pick]).all()
+
+
+def test_emu_sampler_templates_at_product_parameters_and_wave_form(emu, oracle):
+    """Variant 0 = (3329, 278): the same entry points at the product's parameters against the plain oracle, incl. the
+    one-sponge-per-wave SampleNTT on the test06 / test08 recipes' seeds."""
+    ns = 24
+    s34 = np.concatenate([seeds("capp-s", ns, 7), seeds("capp-t", ns, 8)[:, :2]], axis=1).astype(np.uint8)
+    for it in range(7):
+        s34[it] = [(it * i + i) & 0xFF for i in range(34)]   # Test_Archive/SampleNTT_test06.c
+    s34[7] = [2 * i for i in range(34)]                       # Test_Archive/NTT_test08.c
+    want = np.stack([oracle.sample_ntt(s34[i]) for i in range(ns)])
+    for wave in (0, 1):
+        out = np.zeros((ns, 256), np.uint16)
+        assert emu.emu_sample_ntt_bounded(0, wave, C.c_size_t(ns), p8(s34), p16(out)) == 0
+        assert (out == want).all(), wave

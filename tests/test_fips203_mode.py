@@ -87,11 +87,22 @@ def test_emulated_kernels_fips_mode(fips_oracle, pset):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("path", ("chunked", "lane-sliced", "one-workgroup-per-item"))
 @pytest.mark.parametrize("pset", (512, 768, 1024))
-def test_gpu_fips_mode(fips_oracle, pset):
+def test_gpu_fips_mode(fips_oracle, pset, path, monkeypatch):
+    """FIPS 203 mode on every kernel family: `chunked` = the default switches with 96-item chunks (300 items: one sponge per
+    wave for the hashes, the direct sampler per chunk), `lane-sliced` = the full-batch kernels every call of more than 2048
+    items takes (k_hash_decaps<.., 136>, k_sample_main at rate 136), `one-workgroup-per-item` = mlkem_small.hpp."""
     import torch
     pkg = ge.load_package()
-    e = pkg.MLKEM(pset, device=0, chunk_items=96, conformance="fips203")
+    chunk = 96
+    if path == "lane-sliced":
+        monkeypatch.setenv("MLKEM_WIDE_HASH_ITEMS", "0")
+        monkeypatch.setenv("MLKEM_SMALL_ITEMS", "0")
+    elif path == "one-workgroup-per-item":
+        monkeypatch.setenv("MLKEM_SMALL_ITEMS", "100000")
+        chunk = 512
+    e = pkg.MLKEM(pset, device=0, chunk_items=chunk, conformance="fips203")
     n = 300
     d, z, m = seeds("fg-d", n, pset), seeds("fg-z", n, pset), seeds("fg-m", n, pset)
     dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()   # noqa: E731

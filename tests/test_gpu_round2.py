@@ -282,8 +282,12 @@ def test_streaming_pinned_and_pageable_buffers_give_equal_bytes(pkg, torch, orac
     assert lib.mlkem_host_register(Kreg.ctypes.data, Kreg.nbytes) == 0
     try:
         assert lib.mlkem_encaps_stream(768, n, ekp.data_ptr(), mp.data_ptr(), cp.data_ptr(), Kreg.ctypes.data, 256) == 0
+        assert lib.mlkem_stream_last_staged() == 0, "a pinned or registered operand was silently staged like pageable memory"
         c, K = np.zeros((n, 1088), np.uint8), np.zeros((n, 32), np.uint8)
         assert lib.mlkem_encaps_stream(768, n, ek.ctypes.data, m.ctypes.data, c.ctypes.data, K.ctypes.data, 256) == 0
+        assert lib.mlkem_stream_last_staged() == 0b1111
+        assert lib.mlkem_encaps_stream(768, n, ekp.data_ptr(), m.ctypes.data, cp.data_ptr(), K.ctypes.data, 256) == 0
+        assert lib.mlkem_stream_last_staged() == 0b1010   # mixed: m and K pageable
         assert (cp.numpy() == c).all() and (Kreg[:n] == K).all() and not Kreg[n:].any()
         c_o, K_o = oracle.encaps(768, ek_o, m[:64])
         assert (c[:64] == c_o).all() and (K[:64] == K_o).all()

@@ -75,6 +75,12 @@ def test_poly_add_sub_golden_and_raw_12bit(eng, torch, oracle, golden_npz):
     assert lib.mlkem_poly_sub_dev(eng._ctx, 1003, x.data_ptr(), y.data_ptr(), x.data_ptr(), None) == 0
     torch.cuda.synchronize()
     assert (as_u16(x) == want_sub.reshape(-1)[:1003]).all()
+    x2 = dev(torch, na.reshape(-1)[:1003].copy().view(np.int16))
+    torch.cuda.synchronize()
+    assert lib.mlkem_poly_add_dev(eng._ctx, 1003, x2.data_ptr(), y.data_ptr(), y.data_ptr(), None) == 0   # out == second operand
+    torch.cuda.synchronize()
+    assert (as_u16(y) == want_add.reshape(-1)[:1003]).all()
+    y = dev(torch, nb.reshape(-1)[:1003].copy().view(np.int16))
     assert lib.mlkem_poly_add_dev(eng._ctx, 8, None, y.data_ptr(), x.data_ptr(), None) == -101
     # the extremes of the 12-bit field
     e = np.zeros((3, 256), np.uint16)
@@ -336,16 +342,20 @@ def test_every_ciphertext_byte_takes_part_in_the_compare(pkg, torch, oracle, pse
 
 
 # ---- calls of one chunk: matrix sampling on the context's side stream ------------------------------------------------------
-@pytest.mark.parametrize("env", ({}, {"MLKEM_SIDE_STREAM": "0"}, {"MLKEM_WIDE_HASH_ITEMS": "0"}, {"MLKEM_WIDE_HASH_ITEMS": "100000"}),
-                         ids=("side-stream", "one-stream", "lane-sliced-hashes", "one-sponge-per-wave-hashes"))
+@pytest.mark.parametrize("env", ({}, {"MLKEM_SMALL_ITEMS": "0"}, {"MLKEM_SMALL_ITEMS": "0", "MLKEM_SIDE_STREAM": "0"},
+                                 {"MLKEM_SMALL_ITEMS": "0", "MLKEM_WIDE_HASH_ITEMS": "0"}, {"MLKEM_SMALL_ITEMS": "0", "MLKEM_WIDE_HASH_ITEMS": "100000"},
+                                 {"MLKEM_SMALL_ITEMS": "100000"}),
+                         ids=("default", "side-stream", "one-stream", "lane-sliced-hashes", "one-sponge-per-wave-hashes", "one-workgroup-per-item"))
 @pytest.mark.parametrize("pset,n", ((768, 1000), (512, 3), (1024, 130)))
 def test_single_chunk_calls_keep_their_results_with_and_without_the_side_stream(pkg, torch, oracle, env, monkeypatch, pset, n):
     """A call that fits one chunk samples A-hat on the context's side stream while H(ek) / G (encaps) or Decrypt and the
     three sponges (decaps) run on the caller's stream (SideFork, mlkem_pipeline.hpp).  Six rounds of keygen -> encaps ->
     decaps with different data are queued back to back WITHOUT a synchronisation in between: a matrix sampled too early
     (before the previous call's arithmetic has read the scratch) or joined too late would change bytes.  Same bytes with the
-    side stream disabled, and with either family of hash kernels forced for every size (by default calls of at most 1024 items
-    hash with one sponge per wavefront, mlkem_wkeccak.hpp, larger ones with one sponge per lane)."""
+    side stream disabled, with either family of hash kernels forced for every size, and with the one-workgroup-per-item
+    kernels forced on and off (defaults: calls of at most Workspace::small_max items run as one launch per operation,
+    mlkem_small.hpp; up to Workspace::wide_max items the hash kernels carry one sponge per wavefront, mlkem_wkeccak.hpp; larger
+    calls hash with one sponge per lane)."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     e = pkg.MLKEM(pset, device=0, chunk_items=1024)
@@ -365,4 +375,36 @@ def test_single_chunk_calls_keep_their_results_with_and_without_the_side_stream(
         Kd_o, st_o = oracle.decaps(pset, dk_o, host(cb))
         assert (host(ek) == ek_o).all() and (host(dk) == dk_o).all() and (host(c) == c_o).all() and (host(K) == K_o).all()
         assert (host(Kd) == Kd_o).all() and (host(st) == st_o).all()
+    e.close()
+
+
+@pytest.mark.parametrize("n", (1, 2, 255, 256, 257, 2047, 2048, 2049))
+def test_default_path_switches_at_their_boundaries(pkg, torch, oracle, n):
+    """The sizes either side of Workspace::small_max (256: one workgroup per item | batch kernels) and Workspace::wide_max
+    (2048: one sponge per wave + direct sampler | lane-sliced hashes + three-block sampler), default environment, one chunk
+    (chunk_items 4096): ML-KEM-768 keygen -> encaps -> decaps with tampered ciphertexts and one corrupted stored hash."""
+    pset = 768
+    e = pkg.MLKEM(pset, device=0, chunk_items=4096)
+    d, z, m = seeds("bd-d", n, pset), seeds("bd-z", n, pset), seeds("bd-m", n, pset)
+    ek, dk = e.keygen(dev(torch, d), dev(torch, z))
+    c, K = e.encaps(ek, dev(torch, m))
+    cb = c.clone()
+    cb[::5, 17] ^= 0x10
+    dkb = dk.clone()
+    dkb[n // 2, 768 * 3 + 33] ^= 4
+    Kd, st = e.decaps(dkb, cb)
+    torch.cuda.synchronize()
+    sub = np.unique(np.concatenate([np.arange(0, n, max(1, n // 64)), [n // 2, n - 1]]))
+    ek_o, dk_o = oracle.keygen(pset, d[sub], z[sub])
+    c_o, K_o = oracle.encaps(pset, ek_o, m[sub])
+    Kd_o, st_o = oracle.decaps(pset, host(dkb)[sub], host(cb)[sub])
+    assert (host(ek)[sub] == ek_o).all() and (host(dk)[sub] == dk_o).all() and (host(c)[sub] == c_o).all() and (host(K)[sub] == K_o).all()
+    assert (host(st)[sub] == st_o).all() and host(st)[n // 2] == -5 and (np.delete(host(st), n // 2) == 0).all()
+    ok = st_o == 0
+    assert (host(Kd)[sub][ok] == Kd_o[ok]).all()
+    same = (host(Kd) == host(K)).all(axis=1)
+    tam = np.zeros(n, bool)
+    tam[::5] = True
+    keep = np.arange(n) != n // 2
+    assert (same[keep] == ~tam[keep]).all()
     e.close()
