@@ -57,6 +57,40 @@ KECCAK_PERM_LANE_OPS = 24 * 180
 TIMING_PASSES = 3   # passes of the per-kernel HIP-event timing leg
 
 
+def kernel_label(kernel_name):
+    """rocprofv3 kernel name -> the label bench.py's `kernels` table uses (the labels the library's launch() calls carry)."""
+    import re
+    short = re.sub(r"^void ", "", kernel_name).replace("mlkem::", "")
+    base = short.split("<")[0].split("(")[0]
+    if base == "k_sample":
+        return "k_sample_restart"
+    if base == "k_ntt4_batch":
+        return "k_intt_batch" if "<true>" in short else "k_ntt_batch"
+    if base in ("k_encrypt", "k_encrypt2"):
+        return "k_encrypt_cmp" if re.search(r",\s*true>", short) else "k_encrypt"
+    return {"k_keygen2": "k_keygen", "k_decrypt4": "k_decrypt", "k_sample_resume": "k_sample_tail"}.get(base, base)
+
+
+def issue_floors(workload):
+    """{label: floor SIMD cycles per VALU instruction} of this workload's kernels from profiles/r04_isa_floor.json: the instruction
+    mix of the library's own ISA priced at 2 cycles per full-rate wave64 VALU instruction, 4 per half-rate one (v_pk_*,
+    v_alignbit, conversions ...), 3.2 per DPP one (tools/isa_floor.py; Keccak kernels: their round loop).  Empty when the file
+    belongs to another build."""
+    path = os.path.join(ROOT, "profiles", "r04_isa_floor.json")
+    if not os.path.exists(path):
+        return {}
+    d = json.load(open(path))
+    if d.get("source_id") != source_id():
+        return {}
+    k = {"kem512": 2, "kem768": 3, "kem1024": 4, "kem768_shared": 3}.get(workload)
+    out = {}
+    for name, row in d["kernels"].items():
+        if k is not None and "<" in name and not name.split("<")[1].startswith(("%d," % k, "%d>" % k, "true", "false", "3329")):
+            continue
+        out.setdefault(row["label"], row["floor_cycles_per_valu_instr"])
+    return out
+
+
 def expand(label, i):
     return hashlib.shake_128(label.encode() + int(i).to_bytes(8, "little") + BENCH_SEED.to_bytes(8, "little")).digest(32)
 
@@ -616,8 +650,10 @@ def entry(workload, args, elapsed, ok, extra, world):
         achieved = per_unit * units_per_launch / (kernels[dom]["ms_avg"] * 1e-3) / 1e9
         scope = "dominant kernel %s: %g B/unit x %g units per launch (%d launches per step) / its average HIP-event duration %.4f ms" % (
             dom, per_unit, units_per_launch, launches, kernels[dom]["ms_avg"])
-    roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None, "scope": scope,
+    # `bound` names what binds: the NTT-only pass streams at 0.6 of the HBM peak; the full-KEM passes are VALU- and socket-power-bound
+    # (~1 M lane-ops per pair against 5.9 KB) -- achieved / peak / frac stay the HBM figures the contract asks for
+    roofline = {"bound": "hbm" if workload == "ntt" else "valu+power", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None, "scope": scope,
                 "whole_pass": {"achieved": whole, "frac": whole / HBM_PEAK_GBS,
                                "scope": "all kernels of one step: %d B/unit x %d units / step time" % (algo, args.batch)},
                 "dominant_kernel": dom,
@@ -626,7 +662,7 @@ def entry(workload, args, elapsed, ok, extra, world):
     # HBM traffic from the PMC counters is collected off-line (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE cannot run inside
     # this process).  The committed summary is attached only when it was measured on THIS build (same source hash), for
     # this workload, batch and chunking; otherwise traffic stays null.
-    tpath = next((q for q in (os.path.join(ROOT, "profiles", "%s_pmc_traffic_%s.json" % (rnd, workload)) for rnd in ("r03", "r02"))
+    tpath = next((q for q in (os.path.join(ROOT, "profiles", "%s_pmc_traffic_%s.json" % (rnd, workload)) for rnd in ("r04", "r03", "r02"))
                   if os.path.exists(q)), None)
     if tpath:
         t = json.load(open(tpath))
@@ -634,13 +670,38 @@ def entry(workload, args, elapsed, ok, extra, world):
             # `traffic` is per LAUNCH of the dominant kernel, like `achieved`; the all-kernel figure of one step stands beside it
             pl = t.get("per_label", {}).get(dom) if dom else None
             roofline["traffic"] = pl["bytes_per_launch_corrected"] if pl else None
+            roofline["traffic_raw"] = pl["bytes_per_launch_raw"] if pl else None
+            roofline["traffic_exact"] = pl.get("bytes_per_launch_exact") if pl else None
             roofline["traffic_per_step"] = t["hbm_bytes_per_step_corrected"]
+            roofline["traffic_per_step_raw"] = t["hbm_bytes_per_step_raw"]
+            roofline["traffic_per_step_exact"] = t.get("hbm_bytes_per_step_exact")
+            roofline["traffic_over_algorithmic"] = t["hbm_bytes_per_step_corrected"] / (float(algo) * args.batch)
             roofline["traffic_note"] = ("traffic = HBM bytes per launch of %s, traffic_per_step = all kernels of one step; from %s (git %s, "
-                                        "source_id %s): (2*FETCH_SIZE + WRITE_SIZE)*1024 as MI355X_MICROARCH.md prescribes; raw per step = %.3g" % (
-                                            dom, os.path.relpath(tpath, ROOT), t.get("git_head", "?"), t["source_id"], t["hbm_bytes_per_step_raw"]))
+                                        "source_id %s): (2*FETCH_SIZE + WRITE_SIZE)*1024 as MI355X_MICROARCH.md prescribes; *_raw = (FETCH_SIZE + "
+                                        "WRITE_SIZE)*1024 as reported; *_exact = request-size weighted TCC_EA0_RDREQ*/WRREQ* counts (all read requests "
+                                        "are 128-byte requests: profiles/r04_traffic_calibration.txt)" % (
+                                            dom, os.path.relpath(tpath, ROOT), t.get("git_head", "?"), t["source_id"]))
         else:
             roofline["traffic_note"] = "%s was measured on another build (source_id %s != %s) or batch: not attached" % (
                 os.path.relpath(tpath, ROOT), t.get("source_id"), source_id())
+    # measured issue fraction of the hot kernels: floor cycles per VALU instruction of the kernel's mix (ISSUE_FLOOR) / the cycles
+    # per VALU instruction the SQ counters of the committed PMC pass show for this build (tools/pmc_summary.py --json)
+    spath = next((q for q in (os.path.join(ROOT, "profiles", "%s_pmc_sq_%s.json" % (rnd, workload)) for rnd in ("r04",)) if os.path.exists(q)), None)
+    if spath and tpath and json.load(open(tpath)).get("source_id") == source_id():
+        sq = json.load(open(spath))
+        floors = issue_floors(workload)
+        issue = {}
+        for name, row in sq.items():
+            lbl = kernel_label(name)
+            if lbl in kernels and lbl in floors and row.get("cycles_per_valu_instr"):
+                issue[lbl] = {"cycles_per_valu_instr": row["cycles_per_valu_instr"], "floor": floors[lbl],
+                              "issue_frac": floors[lbl] / row["cycles_per_valu_instr"],
+                              "resident_waves_per_simd": row.get("resident_waves_per_simd")}
+        if issue:
+            roofline["issue"] = {"dominant_kernel": issue.get(dom), "kernels": issue,
+                                 "note": "issue_frac = floor SIMD cycles per VALU instruction of the kernel's instruction mix "
+                                         "(profiles/r04_isa_floor.json, tools/isa_floor.py) / measured (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs / "
+                                         "SQ_INSTS_VALU), from %s of the same source_id" % os.path.relpath(spath, ROOT)}
     if workload in ("kem512", "kem768", "kem1024") and dom == "k_sample_main":
         # the dominant kernel's own HBM bytes per launch: per item it reads rho and r (32 B each) and
         # writes the k x k matrix (512 B per polynomial) and the PRF rows (128 B, 192 B for eta = 3)
@@ -660,9 +721,16 @@ def entry(workload, args, elapsed, ok, extra, world):
                                "frac_keccak_only": value / world * keccak_ops / VALU_PEAK_LANE_OPS,
                                "note": "the pass runs into the socket power limit (clock_power below: shader clock well under the "
                                        "nominal 2.4 GHz at ~1.33 kW; DESIGN.md section 5)"}
+    energy = None
     if extra.get("clock_power"):
         roofline["clock_power"] = extra["clock_power"]
-    return {"value": value, "ms_per_step": ms_step, "correct": ok, "roofline": roofline, "kernels": kernels}
+        # socket energy per unit: median socket power while the same steps keep running x step time / units per step and GPU.
+        # The pass sits on the socket power limit, where time = dynamic joules / (limit - idle) (profiles/r04_energy.txt: the
+        # kernel families' stand-alone joules predict the step within 3 %), so joules per unit is the figure of merit.
+        w = extra["clock_power"]["socket_w"]["median"]
+        energy = {"joules_per_unit": w * ms_step * 1e-3 / args.batch, "socket_w": w,
+                  "how": "median socket power (hwmon power1_input) x ms_per_step / batch_per_gpu; includes the idle share (~290 W)"}
+    return {"value": value, "ms_per_step": ms_step, "correct": ok, "roofline": roofline, "kernels": kernels, "energy": energy}
 
 
 def main():
@@ -736,6 +804,9 @@ def main():
     anchor = scaling_anchor(e["value"], per_gpu)
     if anchor:
         line["scaling_anchor"] = anchor
+    if e.get("energy"):
+        line["joules_per_unit"] = e["energy"]["joules_per_unit"]
+        line["energy"] = e["energy"]
     if "cpu_baseline" in extra:
         line["cpu_baseline"] = extra["cpu_baseline"]
     if also:

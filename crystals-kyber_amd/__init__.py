@@ -26,7 +26,7 @@ ERR_HASH = -5
 ABI_SYMBOLS = (
     "mlkem_sizes", "mlkem_params", "mlkem_device_count", "mlkem_strerror", "mlkem_last_hip_error",
     "mlkem_ctx_create", "mlkem_ctx_destroy", "mlkem_ctx_scratch_bytes", "mlkem_timing_begin", "mlkem_timing_end",
-    "mlkem_keygen_dev", "mlkem_encaps_dev", "mlkem_decaps_dev", "mlkem_encaps_status_dev", "mlkem_ctx_set_conformance",
+    "mlkem_keygen_dev", "mlkem_encaps_dev", "mlkem_decaps_dev", "mlkem_encaps_status_dev", "mlkem_ctx_set_conformance", "mlkem_ctx_debug_stages",
     "mlkem_encaps_shared_dev", "mlkem_decaps_shared_dev",
     "mlkem_pke_keygen_dev", "mlkem_pke_encrypt_dev", "mlkem_pke_decrypt_dev",
     "mlkem_ntt_dev", "mlkem_intt_dev", "mlkem_multiply_ntts_dev", "mlkem_sample_ntt_dev", "mlkem_sample_cbd_dev",
@@ -82,6 +82,7 @@ def load_library():
     L.mlkem_decaps_dev.argtypes = [vp, i32, sz, vp, vp, vp, vp, vp]
     L.mlkem_encaps_status_dev.argtypes = [vp, i32, sz, vp, vp, vp, vp, vp, vp]
     L.mlkem_ctx_set_conformance.argtypes = [vp, i32]
+    L.mlkem_ctx_debug_stages.argtypes = [vp, C.c_uint]
     L.mlkem_encaps_shared_dev.argtypes = [vp, i32, sz, vp, vp, vp, vp, vp]
     L.mlkem_decaps_shared_dev.argtypes = [vp, i32, sz, vp, vp, vp, vp, vp]
     L.mlkem_pke_keygen_dev.argtypes = [vp, i32, sz, vp, vp, vp, vp]

@@ -341,6 +341,12 @@ int mlkem_ctx_set_conformance(mlkem_ctx* ctx, int mode) {
     return MLKEM_OK;
 }
 
+int mlkem_ctx_debug_stages(mlkem_ctx* ctx, unsigned mask) {
+    if (!ctx_ok(ctx) || mask > 15u) return MLKEM_ERR_ARG;
+    ctx->ws.stages = mask;
+    return MLKEM_OK;
+}
+
 int mlkem_decaps_dev(mlkem_ctx* ctx, int set, size_t n, const uint8_t* dk, const uint8_t* c, uint8_t* K, int32_t* status, void* stream) {
     ParamSet p;
     if (!param_set(set, p)) return MLKEM_ERR_PARAM_SET;

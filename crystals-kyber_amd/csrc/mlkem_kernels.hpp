@@ -399,34 +399,45 @@ __global__ void __launch_bounds__(WAVE, MLKEM_KECCAK_MINWAVES) k_hash_decaps(siz
     const size_t DK = dk_stride;
     const size_t nb = (n + WAVE - 1) / WAVE;
     const bool check_role = HASH_CHECK && blockIdx.x < nb;
-    const size_t item0 = (size_t)(HASH_CHECK && !check_role ? blockIdx.x - nb : blockIdx.x) * WAVE, item = item0 + lane_id();
-    const size_t it = item < n ? item : n - 1;
+    const size_t item0 = (size_t)(HASH_CHECK && !check_role ? blockIdx.x - nb : blockIdx.x) * WAVE;
     KeccakState s;
     uint32_t h[8], w[8];
-    load32(dk + 768 * K + 32, DK, it, h);
+    // The stored h = dk[768k+32 ..] is loaded only where it is used (after the sponge that precedes its use), and the lane's
+    // item index is recomputed from a fresh lane id there: nothing but the 50 state registers lives across the permutations
+    // (with h and the row pointers held across them the kernel spilled 60-92 bytes per lane).
+    auto my_item = [&]() {
+        const size_t i2 = item0 + (size_t)lane_id_fresh();
+        return i2 < n ? i2 : n - 1;
+    };
     if (check_role) {
         MsgView mv{dk + 384 * K, DK, EK, dk, DK, 0};
         wave_sponge_absorb<136, 0x06>(s, stage, mv, item0, n);
         MLKEM_STATE_WORDS8(s, 0, w)
+        load32(dk + 768 * K + 32, DK, my_item(), h);
         uint32_t diff = 0;
 #pragma unroll
         for (int i = 0; i < 8; i++) diff |= w[i] ^ h[i];
-        if (item < n && status) status[item] = diff ? -5 : 0;
+        const size_t i2 = item0 + (size_t)lane_id_fresh();
+        if (i2 < n && status) status[i2] = diff ? -5 : 0;
         return;
     }
     // Kbar = J(z || c)
     {
         MsgView mv{dk + 768 * K + 64, DK, 32, c, CLEN, CLEN};
         wave_sponge_absorb<JRATE, 0x1F>(s, stage, mv, item0, n);
-        if (item < n) {
+        const size_t i2 = item0 + (size_t)lane_id_fresh();
+        if (i2 < n) {
             MLKEM_STATE_WORDS8(s, 0, w)
-            store32(Kbar_ws, 32, item, w);
+            store32(Kbar_ws, 32, i2, w);
         }
     }
     // (K', r') = G(m' || h)
     uint32_t mm[8];
+    const size_t it = my_item();
     load32(m_ws, 32, it, mm);
+    load32(dk + 768 * K + 32, DK, it, h);
     lane_G64(s, mm, h);
+    const size_t item = item0 + (size_t)lane_id_fresh();
     if (item < n) {
         MLKEM_STATE_WORDS8(s, 0, w)
         store32(Kp_ws, 32, item, w);
@@ -486,16 +497,19 @@ __global__ void __launch_bounds__(WAVE, MLKEM_KECCAK_MINWAVES) k_hash_keygen_fin
 // k_hash_batch — stand-alone H / G / J over equal-length messages (parity tests of the staged sponge)
 //   KIND 0: H = SHA3-256 (32 B out), 1: G = SHA3-512 (64 B out), 2: J = SHAKE128 (32 B out)
 // ------------------------------------------------------------------------------------------------
+// (runtime message length and stride: compiled for 4 waves per SIMD = 128 VGPRs; at the hot kernels' 6 waves = 80 VGPRs the
+// run-time MsgView spilled 56 bytes per lane inside the absorb loop)
 template <int KIND>
-__global__ void __launch_bounds__(WAVE, MLKEM_KECCAK_MINWAVES) k_hash_batch(size_t n, const uint8_t* __restrict__ msg, unsigned len,
+__global__ void __launch_bounds__(WAVE, 4) k_hash_batch(size_t n, const uint8_t* __restrict__ msg, unsigned len,
                                                                             size_t stride, uint8_t* __restrict__ out) {
     constexpr int RATE = KIND == 0 ? 136 : KIND == 1 ? 72 : 168;
     __shared__ __attribute__((aligned(16))) uint2 stage[stage_qwords(RATE)];
-    const size_t item0 = (size_t)blockIdx.x * WAVE, item = item0 + lane_id();
+    const size_t item0 = (size_t)blockIdx.x * WAVE;
     KeccakState s;
     MsgView mv{msg, stride, len, msg, stride, 0};
     uint32_t w[8];
     wave_sponge_absorb<RATE, KIND == 2 ? 0x1F : 0x06>(s, stage, mv, item0, n);
+    const size_t item = item0 + (size_t)lane_id_fresh();
     if (item < n) {
         MLKEM_STATE_WORDS8(s, 0, w)
         store32(out, KIND == 1 ? 64 : 32, item, w);

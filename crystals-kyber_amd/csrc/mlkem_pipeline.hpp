@@ -116,6 +116,9 @@ struct Workspace {
                               // up to 2048 items, slower from 4096, profiles/r03_batch_sweep.txt); env MLKEM_WIDE_HASH_ITEMS
     size_t small_max = 256;   // calls of at most this many items run as ONE launch, one workgroup per item (mlkem_small.hpp);
                               // env MLKEM_SMALL_ITEMS (0: never)
+    // measurement aid (mlkem_ctx_debug_stages, tools/energy_probe.py): which kernel families the batch path launches; the
+    // outputs of a call with stages missing are meaningless.  1 = hash kernels, 2 = sampler, 4 = K-PKE.Encrypt / KeyGen, 8 = Decrypt
+    unsigned stages = 15;
     int fips = 0;      // 0: bit-identical to the reference (PRF, J on SHAKE128; no-op modulus check)
                        // 1: FIPS 203 conformant (PRF, J on SHAKE256; encaps reports status -4 for t-hat coefficients >= q)
 #ifndef MLKEM_EMU
@@ -274,7 +277,8 @@ inline void encaps_run(stream_t st, const ParamSet& p, size_t n, const uint8_t* 
     for (size_t h0 = 0; h0 < n; h0 += ws.hcap) {
         const size_t hn = min_sz(ws.hcap, n - h0);
         const uint8_t* r_h = r_user ? r_user + h0 * 32 : (const uint8_t*)ws.r;
-        if (!r_user && n <= ws.wide_max)   // small call: one sponge per wave, a chain of ~4.5 us permutations instead of ~10.5
+        if (!(ws.stages & 1u)) {
+        } else if (!r_user && n <= ws.wide_max)   // mid-size call: one sponge per wave (mlkem_wkeccak.hpp)
             launch("k_hash_encaps", k_hash_encaps_w<K>, hn, WAVE, st, hn, ek + h0 * p.ek_len, m + h0 * 32, Kout + h0 * 32, ws.r);
         else if (!r_user)
             launch("k_hash_encaps", k_hash_encaps<K>, ceil_div(hn, WAVE), WAVE, st, hn, ek + h0 * p.ek_len, m + h0 * 32, Kout + h0 * 32, ws.r);
@@ -284,9 +288,10 @@ inline void encaps_run(stream_t st, const ParamSet& p, size_t n, const uint8_t* 
             if (fork.active()) {   // PRF rows on the caller's stream (they need r), then wait for the matrix
                 launch_sample_split(st, p, 0, cn, nullptr, 0, 1, r_h + c0 * 32, 2 * K + 1, K, ws);
                 fork.join_main();
-            } else {
+            } else if (ws.stages & 2u) {
                 launch_sample(st, p, cn, eki + 384 * K, p.ek_len, /*transpose=*/1, r_h + c0 * 32, 2 * K + 1, K, ws);
             }
+            if (ws.stages & 4u)
             encrypt_launch<K, ETA1, DU, DV, false>("k_encrypt", st, cn, eki, (size_t)p.ek_len, m + i0 * 32, (const uint16_t*)ws.A, (const uint8_t*)ws.prf,
                    c + i0 * p.c_len, (const uint8_t*)nullptr, (const uint8_t*)nullptr, (const uint8_t*)nullptr, (uint8_t*)nullptr,
                    mod_status ? mod_status + i0 : (int32_t*)nullptr, (size_t)(K * K * 256));
@@ -324,10 +329,11 @@ inline void decaps_run(stream_t st, const ParamSet& p, size_t n, const uint8_t* 
         const uint8_t* ch = c + h0 * p.c_len;
         SideFork fork(ws, st, n);   // one chunk: A-hat^T of the re-encryption is sampled beside Decrypt and the three sponges
         if (fork.active()) launch_sample_split(fork.xof_stream(), p, n, 0, dk + 768 * K, p.dk_len, /*transpose=*/1, nullptr, 2 * K + 1, K, ws);
-        decrypt_launch<K, DU, DV>(st, hn, dkh, (size_t)p.dk_len, ch, ws.m);
+        if (ws.stages & 8u) decrypt_launch<K, DU, DV>(st, hn, dkh, (size_t)p.dk_len, ch, ws.m);
         int32_t* sth = (hash_check && status) ? status + h0 : (int32_t*)nullptr;
         const size_t hgrid = ceil_div(hn, WAVE);
-        if (n <= ws.wide_max) {   // small call: one sponge per wave (mlkem_wkeccak.hpp)
+        if (!(ws.stages & 1u)) {
+        } else if (n <= ws.wide_max) {   // small call: one sponge per wave (mlkem_wkeccak.hpp)
             if (hash_check && !ws.fips)
                 launch("k_hash_decaps", k_hash_decaps_w<K, CLEN, true, 168>, 2 * hn, WAVE, st, hn, dkh, ch, (const uint8_t*)ws.m, ws.Kp, ws.r, ws.Kbar, sth, (size_t)p.dk_len);
             else if (!ws.fips)
@@ -351,9 +357,10 @@ inline void decaps_run(stream_t st, const ParamSet& p, size_t n, const uint8_t* 
             if (fork.active()) {
                 launch_sample_split(st, p, 0, cn, nullptr, 0, 1, ws.r + c0 * 32, 2 * K + 1, K, ws);
                 fork.join_main();
-            } else {
+            } else if (ws.stages & 2u) {
                 launch_sample(st, p, cn, dki + 768 * K, p.dk_len, /*transpose=*/1, ws.r + c0 * 32, 2 * K + 1, K, ws);
             }
+            if (ws.stages & 4u)
             encrypt_launch<K, ETA1, DU, DV, true>("k_encrypt_cmp", st, cn, dki + 384 * K, (size_t)p.dk_len, (const uint8_t*)(ws.m + c0 * 32), (const uint16_t*)ws.A,
                    (const uint8_t*)ws.prf, (uint8_t*)nullptr, c + i0 * p.c_len, (const uint8_t*)(ws.Kp + c0 * 32),
                    (const uint8_t*)(ws.Kbar + c0 * 32), Kout + i0 * 32, (int32_t*)nullptr, (size_t)(K * K * 256));

@@ -84,6 +84,10 @@ MLKEM_API int mlkem_ctx_set_conformance(mlkem_ctx* ctx, int mode);
  * stream.  mlkem_timing_end synchronises and returns per-kernel-label rows: labels[32*i..] (NUL-terminated),
  * total_ms[i], counts[i]; return value = number of rows (<= max) or a negative error (MLKEM_ERR_NO_DEVICE when an event
  * could not be created or recorded: incomplete rows are not reported). */
+/* Measurement aid (tools/energy_probe.py): restrict the batch path of this context's *_dev KEM calls (more than 256 items) to some
+ * of its kernel families -- mask bits: 1 = hash kernels, 2 = sampler, 4 = K-PKE.Encrypt, 8 = K-PKE.Decrypt; 15 = all (default).
+ * The outputs of a call with stages missing are meaningless; only time and power of the remaining launches are of interest. */
+MLKEM_API int mlkem_ctx_debug_stages(mlkem_ctx* ctx, unsigned mask);
 MLKEM_API int mlkem_timing_begin(void);
 MLKEM_API int mlkem_timing_end(char* labels, double* total_ms, int* counts, int max);
 

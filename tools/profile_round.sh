@@ -8,7 +8,7 @@
 #   the host-pointer call latency, the PCIe-inclusive streaming rate and the batch-size sweep.
 # Output: gpurun_out/prof_<tag>/.   The program after `--` is python3 itself (no env / bash -c hop under the profiler).
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
@@ -41,6 +41,9 @@ for wl in kem768 ntt kem1024; do
     run kt_$wl --kernel-trace --stats --output-format csv -d "$OUT/kt_$wl" -o $wl -- python3 "$ROOT/bench.py" --workload $wl --no-cpu --no-also || exit 1
     run fetch_$wl --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/fetch_$wl" -o $wl -- python3 "$ROOT/bench.py" --workload $wl --no-cpu --no-also --steps 3 --warmup 1 || exit 1
     run write_$wl --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/write_$wl" -o $wl -- python3 "$ROOT/bench.py" --workload $wl --no-cpu --no-also --steps 3 --warmup 1 || exit 1
+    # exact request-size counters (tools/pmc_traffic.py: read = 128 B x RDREQ_128B + ..., write = 64 B x WRREQ_64B + ...)
+    run rdreq_$wl --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_128B_sum --kernel-trace --output-format csv -d "$OUT/rdreq_$wl" -o $wl -- python3 "$ROOT/bench.py" --workload $wl --no-cpu --no-also --steps 3 --warmup 1 || exit 1
+    run wrreq_$wl --pmc TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum --kernel-trace --output-format csv -d "$OUT/wrreq_$wl" -o $wl -- python3 "$ROOT/bench.py" --workload $wl --no-cpu --no-also --steps 3 --warmup 1 || exit 1
     # SQ view of the same command: issue utilisation (VALU instructions per SIMD-cycle), waiting, LDS use
     run sq_$wl --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_LDS SQ_INSTS_SALU GRBM_GUI_ACTIVE \
         --kernel-trace --output-format csv -d "$OUT/sq_$wl" -o $wl -- python3 "$ROOT/bench.py" --workload $wl --no-cpu --no-also --steps 3 --warmup 1 || exit 1

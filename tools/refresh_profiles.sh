@@ -18,8 +18,9 @@ fi
 for wl in kem768 ntt kem1024; do
   cp $D/kt_$wl/${wl}_kernel_stats.csv profiles/${T}_${wl}_kernel_stats.csv || exit 1
   python tools/pmc_traffic.py --fetch $D/fetch_$wl/${wl}_counter_collection.csv --write $D/write_$wl/${wl}_counter_collection.csv \
+      --rdreq $D/rdreq_$wl/${wl}_counter_collection.csv --wrreq $D/wrreq_$wl/${wl}_counter_collection.csv \
       --bench $D/fetch_$wl.bench.json --workload $wl --out profiles/${T}_pmc_traffic_$wl.json | tail -1 || exit 1
-  python tools/pmc_summary.py $D/sq_$wl/${wl}_counter_collection.csv --filter k_ > profiles/${T}_pmc_sq_$wl.txt || exit 1
+  python tools/pmc_summary.py $D/sq_$wl/${wl}_counter_collection.csv --filter k_ --json profiles/${T}_pmc_sq_$wl.json > profiles/${T}_pmc_sq_$wl.txt || exit 1
 done
 cp $D/bench_default.json profiles/${T}_bench_default.json
 cp $D/bench_kem512.json profiles/${T}_bench_kem512.json
