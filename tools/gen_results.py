@@ -11,8 +11,7 @@ files under profiles/ (so that prose and profiles cannot drift apart):
   profiles/<tag>_gpu_tier.log            `pytest -m gpu` on the GPU box (test count)
   profiles/<tag>_batch_sweep_head.txt, <tag>_host_latency.txt, <tag>_stream_bench.json   batch-size sweep, host-pointer latency and streaming rate
 
-Writes profiles/<tag>_RESULTS.md and replaces the text between `<!-- BEGIN GENERATED <tag> -->` and `<!-- END GENERATED <tag> -->`
-in DESIGN.md and README.md with it."""
+Writes profiles/<tag>_RESULTS.md -- the ONE generated results block of a round; README.md and DESIGN.md link to it."""
 import csv
 import json
 import os
@@ -20,7 +19,7 @@ import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r03"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r04"
 P = os.path.join(ROOT, "profiles")
 HBM = 8000.0
 ALGO = {"kem768": 5856, "kem1024": 12768, "kem512": 6560, "ntt": 2048}
@@ -92,11 +91,22 @@ def roofline_lines(j, wl, traffic):
         out.append("* HBM traffic by PMC (`profiles/%s_pmc_traffic_%s.json`, git %s, source_id %s): %.2f GB per step corrected (raw %.2f GB) against %.2f GB algorithmic = **%.2f x**" % (
             TAG, wl, traffic["git_head"], traffic["source_id"], traffic["hbm_bytes_per_step_corrected"] / 1e9, traffic["hbm_bytes_per_step_raw"] / 1e9,
             algo / 1e9, traffic["hbm_bytes_per_step_corrected"] / algo))
+        if traffic.get("hbm_bytes_per_step_exact"):
+            out.append("  * exact, from the request-size counters (128 B x RDREQ_128B + ..., 64 B x WRREQ_64B + ...): %.2f GB per step — every read "
+                       "request is a 128-byte request, so the doubled FETCH_SIZE is the truth (`profiles/r04_traffic_calibration.txt`)" % (
+                           traffic["hbm_bytes_per_step_exact"] / 1e9))
         dom = rf.get("dominant_kernel")
         pl = traffic.get("per_label", {}).get(dom)
         if pl:
             out.append("  * dominant kernel `%s`: %.3f GB per launch corrected (raw %.3f GB), %d launches per step" % (
                 dom, pl["bytes_per_launch_corrected"] / 1e9, pl["bytes_per_launch_raw"] / 1e9, pl["launches_per_step"]))
+        of = [(k, v) for k, v in traffic.get("per_kernel", {}).items() if v.get("over_fetch")]
+        if of:
+            out.append("  * read bytes / bytes of the kernel's input arguments: " + ", ".join("`%s` %.2f" % (k.split("<")[0], v["over_fetch"]) for k, v in of))
+    if rf.get("issue"):
+        out.append("* issue fraction (floor cycles per VALU instruction of the kernel's ISA mix / measured; `bound: %s`): " % rf.get("bound") + ", ".join(
+            "`%s` %.2f (%.2f / %.2f at %.1f waves)" % (k, v["issue_frac"], v["floor"], v["cycles_per_valu_instr"], v.get("resident_waves_per_simd") or 0)
+            for k, v in sorted(rf["issue"]["kernels"].items(), key=lambda kv: -kv[1]["issue_frac"])))
     cp = rf.get("clock_power")
     if cp:
         out.append("* clock / power behind the timed region: shader clock median %s MHz (nominal %s), socket power median %s W (cap %s W)" % (
@@ -135,6 +145,9 @@ def main():
     L.append("_Generated by `tools/gen_results.py %s` from the files under `profiles/%s_*`; do not edit by hand._\n" % (TAG, TAG))
     L.append("**Headline (BASELINE configs[2])**: `python bench.py` → **%.3g %s**, %.2f ms per step of 2^20 pairs, `correct: %s` (`profiles/%s_bench_default.json`).\n" % (
         d["value"], d["unit"], d["ms_per_step"], d["correct"], TAG))
+    if d.get("joules_per_unit"):
+        L.append("Socket energy: **%.1f uJ per pair** (%.0f W median x step time / 2^20; `profiles/%s_energy.txt` splits it by kernel family).\n" % (
+            1e6 * d["joules_per_unit"], d["energy"]["socket_w"], TAG))
     st = stats("kem768")
     L.append(bench_table(d, "kem768", st))
     L.append("")
@@ -167,10 +180,15 @@ def main():
         if not j:
             continue
         L.append("**N > 1 line on the one GPU — %s**: aggregate %.3g %s, %.2f ms per step, `correct: %s`; `per_gpu`:\n" % (title, j["value"], j["unit"], j["ms_per_step"], j["correct"]))
-        L.append("| rank | device | %s | ms / step | sclk MHz | socket W | correct |" % j["unit"])
-        L.append("|---|---|---|---|---|---|---|")
+        L.append("| rank | device | %s | ms / step | solo %s (in-job N = 1 anchor) | sclk MHz | socket W | correct |" % (j["unit"], j["unit"]))
+        L.append("|---|---|---|---|---|---|---|---|")
         for p in j["per_gpu"]:
-            L.append("| %d | %d | %.3g | %.2f | %s | %s | %s |" % (p["rank"], p["device"], p["value"], p["ms_per_step"], p["sclk_mhz"], p["socket_w"], p["correct"]))
+            L.append("| %d | %d | %.3g | %.2f | %s | %s | %s | %s |" % (p["rank"], p["device"], p["value"], p["ms_per_step"],
+                     ("%.3g" % p["solo_value"]) if p.get("solo_value") else "—", p["sclk_mhz"], p["socket_w"], p["correct"]))
+        a = j.get("scaling_anchor")
+        if a:
+            L.append("\n`scaling_anchor`: efficiency = aggregate / sum of solo values = **%.3f** (ranks sharing ONE GPU: 1/N is the expected figure), per rank %s" % (
+                a["efficiency"], ", ".join("%.3f" % x for x in a["per_gpu_efficiency"])))
         L.append("")
     sweep = os.path.join(P, "%s_batch_sweep_head.txt" % TAG)
     if os.path.exists(sweep):
@@ -196,6 +214,13 @@ def main():
                 v, k = best(kind)
                 L.append("* streaming %d items, %s buffers: %.3g pairs/s at chunk %s (`profiles/%s_stream_bench.json`)" % (sb["items"], kind, v, k.rsplit("_", 1)[1], TAG))
         L.append("")
+    for name, title in (("small_sweep.txt", "Small calls: one workgroup per item against the batch path (`tools/small_sweep.sh`)"),
+                        ("energy.txt", "Energy by kernel family, each looped alone at its 2^20 shapes (`tools/energy_probe.py`)"),
+                        ("keccak_wave_ubench.txt", "Keccak-f[1600] of a lone wave: lane-sliced / half-wave (round 3) / wave-wide (`tools/keccak_wave_ubench.hip`)")):
+        path = os.path.join(P, "%s_%s" % (TAG, name))
+        if os.path.exists(path):
+            body = [ln.rstrip()[:230] for ln in open(path) if not ln.startswith("{")]
+            L.append("**%s** (`profiles/%s_%s`):\n\n```\n%s\n```\n" % (title, TAG, name, "\n".join(body)))
     log = os.path.join(P, "%s_gpu_tier.log" % TAG)
     if os.path.exists(log):
         m = re.search(r"(\d+) passed", open(log).read())
@@ -203,16 +228,6 @@ def main():
             L.append("**GPU tier**: %s tests passed on MI355X (`profiles/%s_gpu_tier.log`).\n" % (m.group(1), TAG))
     text = "\n".join(L).rstrip() + "\n"
     open(os.path.join(P, "%s_RESULTS.md" % TAG), "w").write(text)
-    for doc in ("DESIGN.md", "README.md"):
-        path = os.path.join(ROOT, doc)
-        s = open(path).read()
-        b, e = "<!-- BEGIN GENERATED %s -->" % TAG, "<!-- END GENERATED %s -->" % TAG
-        if b in s and e in s:
-            s = s[:s.index(b) + len(b)] + "\n" + text + s[s.index(e):]
-            open(path, "w").write(s)
-            print("updated", doc)
-        else:
-            print("no marker for", TAG, "in", doc)
     print("wrote profiles/%s_RESULTS.md (%d lines)" % (TAG, text.count("\n")))
 
 
