@@ -708,7 +708,14 @@ int stream_op(StreamEngine& e, size_t n, size_t chunk, const std::vector<Span>& 
     const size_t nchunks = (n + chunk - 1) / chunk;
     const int nsets = nchunks < (size_t)NSETS ? (int)nchunks : NSETS;
     std::vector<char> staged(spans.size());
-    for (size_t j = 0; j < spans.size(); j++) staged[j] = !host_pinned(spans[j].in ? spans[j].in : spans[j].out, n * spans[j].bytes);
+    // a tiny call (a few KB per operand: the ml_kem.h shim's one-item calls) copies its operands through the pinned staging
+    // buffers without asking the runtime what kind of memory the caller handed in: eight pointer-attribute queries cost more
+    // than the memcpy of 3 KB
+    size_t widest = 0;
+    for (const Span& sp : spans) widest = sp.bytes > widest ? sp.bytes : widest;
+    const bool tiny = n * widest <= 16384;
+    for (size_t j = 0; j < spans.size(); j++)
+        staged[j] = tiny || !host_pinned(spans[j].in ? spans[j].in : spans[j].out, n * spans[j].bytes);
     t_last_staged = 0;
     for (size_t j = 0; j < spans.size() && j < 31; j++) t_last_staged |= staged[j] ? (1 << j) : 0;
     int rc = engine_prepare(e, dev, chunk, spans, staged, nsets);
@@ -733,6 +740,40 @@ int stream_op(StreamEngine& e, size_t n, size_t chunk, const std::vector<Span>& 
         // side-stream sampling only for a stand-alone chunk, and then on the front-end's own idle copy stream
         e.ctx->ws.side_on = single && e.ctx->side_allowed;
         if (e.ctx->ws.side_on) e.ctx->ws.side = e.h2d;
+    }
+    // Small call (what the ml_kem.h shim makes: one item): no copy commands at all.  The kernels of mlkem_small.hpp read their
+    // inputs from, and write their outputs to, PINNED HOST memory over PCIe -- the caller's own buffers where they are pinned or
+    // registered (and 16-byte aligned), the set's pinned staging buffer otherwise -- so that the call is: memcpy in, ONE launch,
+    // stream synchronise, memcpy out.  (Per operation and item the kernels read 1.2-3.5 KB and write 0.03-1.1 KB; four copy
+    // commands and an event cost more than the PCIe round trips inside the kernel: profiles/r04_host_latency.txt.)
+    // MLKEM_ZERO_COPY=0 keeps the copy commands.
+    static const bool zero_copy = [] { const char* z = getenv("MLKEM_ZERO_COPY"); return !(z && atoi(z) == 0); }();
+    if (rc == MLKEM_OK && single && zero_copy && e.ctx && n <= e.ctx->ws.small_max && n <= e.ctx->ws.cap) {
+        BufSet& s = e.set[0];
+        bool ok = true;
+        for (size_t j = 0; j < spans.size() && ok; j++) {
+            void* host = spans[j].in ? const_cast<void*>(spans[j].in) : spans[j].out;
+            const bool direct = !staged[j] && (reinterpret_cast<uintptr_t>(host) & 15u) == 0;
+            if (!direct && !s.buf[j].pin) ok = hip_ok(hipHostMalloc(&s.buf[j].pin, s.buf[j].cap, hipHostMallocDefault), "hipHostMalloc");
+            if (!ok) break;
+            void* h = direct ? host : s.buf[j].pin;
+            if (!direct && spans[j].in) memcpy(h, spans[j].in, n * spans[j].bytes);
+            void* d = nullptr;
+            ok = hip_ok(hipHostGetDevicePointer(&d, h, 0), "hipHostGetDevicePointer") && d;
+            devp[j] = d;
+            staged[j] = !direct;
+        }
+        if (ok) {
+            rc = launch(e.ctx, n, devp, e.k);
+            if (rc == MLKEM_OK && !hip_ok(hipStreamSynchronize(e.k), "hipStreamSynchronize")) rc = MLKEM_ERR_NO_DEVICE;
+            if (rc == MLKEM_OK)
+                for (size_t j = 0; j < spans.size(); j++)
+                    if (spans[j].out && staged[j]) memcpy(spans[j].out, s.buf[j].pin, n * spans[j].bytes);
+            if (rc != MLKEM_OK) engine_release(e);
+            return rc;
+        }
+        (void)hipGetLastError();   // no device view of a buffer: take the copy path below
+        for (size_t j = 0; j < spans.size(); j++) staged[j] = !host_pinned(spans[j].in ? spans[j].in : spans[j].out, n * spans[j].bytes);
     }
     size_t i = 0;
     for (size_t off = 0; off < n && rc == MLKEM_OK; off += chunk, i++) {

@@ -270,6 +270,8 @@ __device__ __forceinline__ uint32_t k2_cbd_load_nat2(const uint8_t* prf, int t) 
 // crosses a nibble); even nibbles are the low nibbles of the four bytes = the .x halves of the lane's four pairs, odd nibbles
 // the .y halves, so the conversion is v_cvt_f32_ubyteN and the "- 2" four packed adds: 24 instructions for 8 coefficients
 // (cbd_eval_f<2> twice: 38).
+// BIASED: the coefficients + 2 (0..4), for consumers that fold the -2 into an FMA they issue anyway (k2_compress4<D, true>)
+template <bool BIASED = false>
 __device__ __forceinline__ void k2_cbd2_eval8(uint32_t t, v2f (&p)[4]) {
     const uint32_t s = (t & 0x55555555u) + ((t >> 1) & 0x55555555u);
     const uint32_t d = ((s & 0x33333333u) + 0x22222222u) - ((s >> 2) & 0x33333333u);
@@ -280,12 +282,15 @@ __device__ __forceinline__ void k2_cbd2_eval8(uint32_t t, v2f (&p)[4]) {
     asm volatile("" : "+v"(fl[0]), "+v"(fl[1]), "+v"(fl[2]), "+v"(fl[3]), "+v"(fh[0]), "+v"(fh[1]), "+v"(fh[2]), "+v"(fh[3]));
 #endif
 #pragma unroll
-    for (int j = 0; j < 4; j++) p[j] = v2f{fl[j], fh[j]} - splat2(2.0f);
+    for (int j = 0; j < 4; j++) {
+        if constexpr (BIASED) p[j] = v2f{fl[j], fh[j]};
+        else p[j] = v2f{fl[j], fh[j]} - splat2(2.0f);
+    }
 }
 template <int ETA>
 __device__ __forceinline__ void k2_cbd_eval(const K2CbdRaw<ETA>& r, v2f (&p)[4]) {
     if constexpr (ETA == 2) {
-        k2_cbd2_eval8(r.w[0], p);
+        k2_cbd2_eval8<false>(r.w[0], p);
     } else {
         float a[4], b[4];
         cbd_eval_f<3>(r.w[0], a);
@@ -331,28 +336,34 @@ __device__ __forceinline__ void k2_decode12(uint32_t w0, uint32_t w1, uint32_t w
     p[0] = v2f{(float)c0, (float)c1}; p[1] = v2f{(float)c2, (float)c3}; p[2] = v2f{(float)c4, (float)c5}; p[3] = v2f{(float)c6, (float)c7};
 }
 
-// Compress_D (ml_kem.c:83-97) of any representative |x| <= 4095 on both halves of a pair: compress_f (mlkem_fntt.hpp) packed
-template <int D>
+// Compress_D (ml_kem.c:83-97) of any representative |x| <= 4095 on both halves of a pair: compress_f (mlkem_fntt.hpp) packed.
+// BIASED: x holds (value + 2) -- a CBD_2 sample that kept its bias (k2_cbd2_eval8<true>) was added; the -2 rides in the first FMA.
+// The quotient k0 = round(2^D x / q) and its repair k in {-1, 0, 1} both leave their FMA as MAGIC + integer (MAGIC = 1.5 * 2^23),
+// i.e. as bit patterns bits(MAGIC) + integer; 2 * bits(MAGIC) = 0x96800000 has its low 23 bits clear, so
+// (bits(MAGIC + k0) + bits(MAGIC + k)) mod 2^D = (k0 + k) mod 2^D: one integer add and one mask per coefficient replace two packed
+// subtractions / additions and a float -> int conversion (proven over the whole domain by sweep 8 of mlkem_selftest).
+__device__ __forceinline__ uint32_t f_bits(float x) {
+    union { float f; uint32_t u; } v;
+    v.f = x;
+    return v.u;
+}
+template <int D, bool BIASED = false>
 __device__ __forceinline__ void k2_compress4(const v2f (&x)[4], unsigned (&c)[8]) {
-    v2f tt[4], k0[4], r[4], k[4];
+    v2f tt[4], k0m[4], k0[4], r[4], km[4];
 #pragma unroll
-    for (int j = 0; j < 4; j++) tt[j] = fma2(x[j], splat2((float)(1 << D)), splat2(0.0f));
+    for (int j = 0; j < 4; j++) tt[j] = fma2(x[j], splat2((float)(1 << D)), splat2(BIASED ? -(float)(2 << D) : 0.0f));
 #pragma unroll
-    for (int j = 0; j < 4; j++) k0[j] = fma2(tt[j], splat2(F_INVQ), splat2(F_MAGIC));
+    for (int j = 0; j < 4; j++) k0m[j] = fma2(tt[j], splat2(F_INVQ), splat2(F_MAGIC));
 #pragma unroll
-    for (int j = 0; j < 4; j++) k0[j] = k0[j] - splat2(F_MAGIC);
+    for (int j = 0; j < 4; j++) k0[j] = k0m[j] - splat2(F_MAGIC);
 #pragma unroll
     for (int j = 0; j < 4; j++) r[j] = fma2(k0[j], splat2(-F_Q), tt[j]);
 #pragma unroll
-    for (int j = 0; j < 4; j++) k[j] = fma2(r[j], splat2(F_INVQ), splat2(F_MAGIC));
-#pragma unroll
-    for (int j = 0; j < 4; j++) k[j] = k[j] - splat2(F_MAGIC);
-#pragma unroll
-    for (int j = 0; j < 4; j++) k[j] = k0[j] + k[j];
+    for (int j = 0; j < 4; j++) km[j] = fma2(r[j], splat2(F_INVQ), splat2(F_MAGIC));
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-        c[2 * j] = (unsigned)(int)k[j].x & ((1u << D) - 1u);
-        c[2 * j + 1] = (unsigned)(int)k[j].y & ((1u << D) - 1u);
+        c[2 * j] = (f_bits(k0m[j].x) + f_bits(km[j].x)) & ((1u << D) - 1u);
+        c[2 * j + 1] = (f_bits(k0m[j].y) + f_bits(km[j].y)) & ((1u << D) - 1u);
     }
 }
 
@@ -471,10 +482,10 @@ __device__ __forceinline__ uint32_t k2_piece_diff(int t, const K2Piece<D>& a, co
     return d;
 }
 // Compress_D + ByteEncode_D of the lane's pairs, then store or compare
-template <int D, bool COMPARE>
+template <int D, bool COMPARE, bool BIASED = false>
 __device__ __forceinline__ uint32_t k2_emit(const v2f (&p)[4], int t, uint8_t* out, const K2Piece<D>& ref, bool store) {
     unsigned c[8];
-    k2_compress4<D>(p, c);
+    k2_compress4<D, BIASED>(p, c);
     K2Piece<D> o;
     k2_encode<D>(c, t, o);
     if constexpr (COMPARE) return k2_piece_diff<D>(t, o, ref);
@@ -588,19 +599,17 @@ encrypt2_body(float2 (*xch)[2][128], size_t item0, size_t n, const uint8_t* __re
     }
 #pragma unroll
     for (int a = 0; a < NG; a++) {
-        K2CbdRaw<2> re;
-        re.w[0] = raw_e[a];
         v2f e[4];
-        k2_cbd_eval<2>(re, e);
+        k2_cbd2_eval8<true>(raw_e[a], e);              // e1 / e2 + 2: the bias leaves in Compress's first FMA
 #pragma unroll
         for (int j = 0; j < 4; j++) acc[a][j] = acc[a][j] + e[j];
         if (a < K) {
-            diff |= k2_emit<DU, COMPARE>(acc[a], nb, COMPARE ? nullptr : my_c + a * 32 * DU, cu_ref[a], valid);
+            diff |= k2_emit<DU, COMPARE, true>(acc[a], nb, COMPARE ? nullptr : my_c + a * 32 * DU, cu_ref[a], valid);
         } else {
 #pragma unroll
             for (int j = 0; j < 4; j++)                // Decompress_1(1) = 1665
                 acc[a][j] = acc[a][j] + v2f{((mb >> (2 * j)) & 1u) ? 1665.0f : 0.0f, ((mb >> (2 * j + 1)) & 1u) ? 1665.0f : 0.0f};
-            diff |= k2_emit<DV, COMPARE>(acc[a], nb, COMPARE ? nullptr : my_c + K * 32 * DU, cv_ref, valid);
+            diff |= k2_emit<DV, COMPARE, true>(acc[a], nb, COMPARE ? nullptr : my_c + K * 32 * DU, cv_ref, valid);
         }
     }
     if (mod_status) {

@@ -146,6 +146,16 @@ __global__ void __launch_bounds__(256) k_selftest(int sweep, unsigned long long*
             if (c[0] != compress_ref<10>(x) || c[1] != compress_ref<10>(-x) || c[3] != c[0]) bad++;
             k2_compress4<11>(in, c);
             if (c[0] != compress_ref<11>(x) || c[1] != compress_ref<11>(-x) || c[4] != c[1]) bad++;
+            // the biased form (input = value + 2, the -2 folded into the first FMA): what K-PKE.Encrypt runs
+            const v2f inb[4] = {v2f{(float)(x + 2), (float)(2 - x)}, v2f{(float)(x + 2), (float)(x + 2)}, v2f{(float)(2 - x), (float)(x + 2)}, v2f{2.f, (float)(x + 2)}};
+            k2_compress4<4, true>(inb, c);
+            if (c[0] != compress_ref<4>(x) || c[1] != compress_ref<4>(-x) || c[2] != c[0] || c[4] != c[1] || c[6] != 0u || c[7] != c[0]) bad++;
+            k2_compress4<5, true>(inb, c);
+            if (c[0] != compress_ref<5>(x) || c[1] != compress_ref<5>(-x) || c[5] != c[0]) bad++;
+            k2_compress4<10, true>(inb, c);
+            if (c[0] != compress_ref<10>(x) || c[1] != compress_ref<10>(-x) || c[3] != c[0]) bad++;
+            k2_compress4<11, true>(inb, c);
+            if (c[0] != compress_ref<11>(x) || c[1] != compress_ref<11>(-x) || c[4] != c[1]) bad++;
         }
         for (long long i = (long long)tid; i <= (1ll << 20); i += (long long)nthreads) {
             const v2f in[4] = {v2f{(float)i, (float)-i}, v2f{(float)-i, (float)i}, v2f{(float)i, (float)i}, v2f{0.f, (float)-i}};
@@ -158,8 +168,11 @@ __global__ void __launch_bounds__(256) k_selftest(int sweep, unsigned long long*
             const uint32_t v = (uint32_t)(i & 0xFFFF), fill = (uint32_t)((i >> 16) % 3) * 0x5A5Au + ((i >> 16) % 3 == 2 ? 0xFFFFu - 2 * 0x5A5Au : 0u);
             const bool upper = (i >> 16) >= 3;
             const uint32_t t = upper ? (v << 16) | fill : v | (fill << 16);
-            v2f p[4];
-            k2_cbd2_eval8(t, p);
+            v2f p[4], pb[4];
+            k2_cbd2_eval8<false>(t, p);
+            k2_cbd2_eval8<true>(t, pb);
+            for (int j = 0; j < 4; j++)
+                if (pb[j].x != p[j].x + 2.0f || pb[j].y != p[j].y + 2.0f) bad++;
             const float got[8] = {p[0].x, p[0].y, p[1].x, p[1].y, p[2].x, p[2].y, p[3].x, p[3].y};
             for (int c = 0; c < 8; c++) {
                 const uint32_t nib = (t >> (4 * c)) & 0xFu;

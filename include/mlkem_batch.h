@@ -239,7 +239,8 @@ MLKEM_API void mlkem_stream_release(void);
  * staging copy for it */
 /* Which operands of the calling thread's last *_stream / host-pointer KEM call were copied through the engine's pinned staging
  * buffers: bit j = span j in argument order (keygen: d z ek dk ; encaps: ek m c K ; decaps: dk c K status); 0 = every operand
- * was handed to the DMA engines in place; -1 before the first call. */
+ * was handed to the DMA engines in place; -1 before the first call.  Calls of at most 16 KB per operand always copy (cheaper than
+ * asking the runtime what kind of memory each pointer is). */
 MLKEM_API int mlkem_stream_last_staged(void);
 MLKEM_API int mlkem_host_register(void* p, size_t bytes);
 MLKEM_API int mlkem_host_unregister(void* p);
