@@ -515,9 +515,9 @@ def test_emu_one_sponge_per_wave_hash_kernels(emu, oracle, pset, fips):
 def test_emu_one_workgroup_per_item_kernels(emu, oracle, pset, fips):
     """mlkem_small.hpp (calls of at most `small_max` items): KeyGen, Encaps and Decaps each as ONE launch, a workgroup of eight
     waves per item -- wave-level SampleNTT (ballot + prefix-count compaction), PRF, H / G / J and the K-PKE bodies behind
-    workgroup barriers.  Two items: an untouched and a tampered ciphertext, then a corrupted stored H(ek); bit for bit against
-    the oracle (reference mode for 512 / 768, FIPS 203 mode -- PRF and J on SHAKE256 -- for 1024)."""
-    n = 2
+    workgroup barriers.  An untouched and a tampered ciphertext (two items for 768, one for the others), then a corrupted stored
+    H(ek) with the untouched ciphertext; bit for bit against the oracle (reference mode for 512 / 768, FIPS 203 mode -- PRF and J on SHAKE256 -- for 1024)."""
+    n = 2 if pset == 768 else 1                        # 512 host threads per item: the second item only where its index matters once
     ekl, dkl, cl = SIZES[pset]
     emu.emu_conformance(fips)
     emu.emu_small(C.c_size_t(16))
@@ -536,15 +536,15 @@ def test_emu_one_workgroup_per_item_kernels(emu, oracle, pset, fips):
         if fips:
             assert (st == 0).all()
         cb, dkb = c.copy(), dk.copy()
-        cb[1, 40] ^= 4                                     # item 1: implicit rejection
+        cb[n - 1, 40] ^= 4                                 # last item: implicit rejection (the only item where n = 1)
         Kd, st = np.zeros((n, 32), np.uint8), np.ones(n, np.int32)
         assert emu.emu_decaps(pset, C.c_size_t(n), p8(dkb), p8(cb), p8(Kd), st.ctypes.data_as(C.POINTER(C.c_int32)), 1) == 0
         Kd_o, st_o = oracle.decaps(pset, dkb, cb)
         assert (st == 0).all() and (st_o == 0).all() and (Kd == Kd_o).all()
-        assert (Kd[0] == K[0]).all() and (Kd[1] != K[1]).any()
+        assert (Kd[n - 1] != K[n - 1]).any() and (n == 1 or (Kd[0] == K[0]).all())
         dkb[0, dkl - 40] ^= 1                              # item 0: stored H(ek) corrupted -> status -5, key = Decaps_internal's
-        assert emu.emu_decaps(pset, C.c_size_t(1), p8(dkb), p8(cb), p8(Kd), st.ctypes.data_as(C.POINTER(C.c_int32)), 1) == 0
-        assert st[0] == -5 and (Kd[0] == oracle.decaps_internal(pset, dkb[0], cb[0])).all()
+        assert emu.emu_decaps(pset, C.c_size_t(1), p8(dkb), p8(c), p8(Kd), st.ctypes.data_as(C.POINTER(C.c_int32)), 1) == 0
+        assert st[0] == -5 and (Kd[0] == oracle.decaps_internal(pset, dkb[0], c[0])).all()   # G ran on the corrupted stored h
     finally:
         emu.emu_small(C.c_size_t(0))
         emu.emu_conformance(0)
@@ -558,7 +558,7 @@ def test_emu_sampler_fifth_block_cap_and_seed_mutation_retry(emu, oracle, varian
     product's sampler templates are instantiated with a LOWER acceptance bound and triple cap so that about half of the sponges
     exhaust their triples: every sponge then runs a fourth and a fifth block, the cap inside the fifth, and a large share the
     retry -- some twice or more.  All four forms against the oracle's parameterised restatement (orc_sample_ntt_bounded; its
-    (3329, 279) instance is the oracle every other test uses), ~1500 sponges per variant:
+    (3329, 279) instance is the oracle every other test uses), ~900 sponges per variant:
       * batch path: k_sample_main (three blocks) -> k_sample_resume (blocks four, five, cap) -> restart list -> k_sample
         (list mode, the retry), with a large and a small resume capacity;
       * k_sample in direct mode (calls of <= 2048 items);
@@ -566,7 +566,7 @@ def test_emu_sampler_fifth_block_cap_and_seed_mutation_retry(emu, oracle, varian
     Parity with the reference ON THIS BRANCH rests on reading ml_kem.c:221-242 (oracle and kernels were written from it);
     no reference run can reach it."""
     limit = cap + 1                                           # the reference counts the triple that trips the limit
-    k, n = 3, 40
+    k, n = 3, 24
     rho = seeds("cap-rho%d" % variant, n, 31)
     want = np.zeros((n, k * k, 256), np.uint16)
     retries = []
@@ -578,10 +578,10 @@ def test_emu_sampler_fifth_block_cap_and_seed_mutation_retry(emu, oracle, varian
                 assert Bo[32] == (a + r) & 0xFF and Bo[33] == (b + r) & 0xFF and (Bo[:32] == rho[i]).all()
                 retries.append(r)
     retries = np.array(retries)
-    assert (retries >= 1).sum() >= 60 and (retries >= 2).sum() >= 10, np.bincount(retries)
+    assert (retries >= 1).sum() >= 40 and (retries >= 2).sum() >= 8, np.bincount(retries)
     assert want.max() < bound
     emu.emu_config(C.c_size_t(0), C.c_size_t(0))
-    for resume_cap, direct in ((512, 0), (16, 0), (64, 1)):
+    for resume_cap, direct in ((256, 0), (16, 0), (64, 1)):
         emu.emu_resume_cap(resume_cap)
         A = np.zeros((n, k * k, 256), np.uint16)
         left = emu.emu_sample_matrix_bounded(variant, k, C.c_size_t(n), p8(rho), 1, p16(A), direct)
@@ -593,21 +593,21 @@ def test_emu_sampler_fifth_block_cap_and_seed_mutation_retry(emu, oracle, varian
             assert restarted >= max(0, handed - resume_cap) + (retries >= 1).sum() * (resume_cap >= handed)
         assert (A == want).all(), (resume_cap, direct, np.argwhere((A != want).any(axis=2))[:5])
     # stand-alone seeds, arbitrary bytes 32 and 33 (the mutation wraps modulo 256)
-    ns = 440
+    ns = 256
     s34 = np.concatenate([seeds("cap-s%d" % variant, ns, 7), seeds("cap-t%d" % variant, ns, 8)[:, :2]], axis=1).astype(np.uint8)
     s34[:8, 32] = 255
     s34[8:16, 33] = 254
     ws = [oracle.sample_ntt_bounded(s34[i], bound, limit) for i in range(ns)]
     wpoly = np.stack([w[0] for w in ws])
-    assert sum(w[1] >= 1 for w in ws) >= 100
+    assert sum(w[1] >= 1 for w in ws) >= 60
     out = np.zeros((ns, 256), np.uint16)
     assert emu.emu_sample_ntt_bounded(variant, 0, C.c_size_t(ns), p8(s34), p16(out)) == 0
     assert (out == wpoly).all()
-    # one sponge per wave (64 host threads per sponge, a barrier per cross-lane operation: slow): 14 seeds chosen by their
-    # retry count -- none, one, two or more
+    # one sponge per wave (64 host threads per sponge, a barrier per cross-lane operation: slow): 4 seeds chosen by their
+    # retry count -- none, one (twice), two or more
     r_of = np.array([w[1] for w in ws])
-    pick = np.concatenate([np.nonzero(r_of == 0)[0][:5], np.nonzero(r_of == 1)[0][:5], np.nonzero(r_of >= 2)[0][:4]])
-    assert len(pick) == 14
+    pick = np.concatenate([np.nonzero(r_of == 0)[0][:1], np.nonzero(r_of == 1)[0][:2], np.nonzero(r_of >= 2)[0][:1]])
+    assert len(pick) == 4
     sw = np.ascontiguousarray(s34[pick])
     out = np.zeros((len(pick), 256), np.uint16)
     assert emu.emu_sample_ntt_bounded(variant, 1, C.c_size_t(len(pick)), p8(sw), p16(out)) == 0
@@ -617,7 +617,7 @@ def test_emu_sampler_fifth_block_cap_and_seed_mutation_retry(emu, oracle, varian
 def test_emu_sampler_templates_at_product_parameters_and_wave_form(emu, oracle):
     """Variant 0 = (3329, 278): the same entry points at the product's parameters against the plain oracle, incl. the
     one-sponge-per-wave SampleNTT on the test06 / test08 recipes' seeds."""
-    ns = 24
+    ns = 8
     s34 = np.concatenate([seeds("capp-s", ns, 7), seeds("capp-t", ns, 8)[:, :2]], axis=1).astype(np.uint8)
     for it in range(7):
         s34[it] = [(it * i + i) & 0xFF for i in range(34)]   # Test_Archive/SampleNTT_test06.c
