@@ -315,7 +315,7 @@ inline void decaps_run(stream_t st, const ParamSet& p, size_t n, const uint8_t* 
     if (n && n <= ws.small_max && n <= ws.cap) {   // small call: one launch, one workgroup per item
         const int rate = ws.fips ? 136 : 168;
         int32_t* sts = hash_check ? status : (int32_t*)nullptr;
-#define MLKEM_DS(HC, JR) launch("k_decaps_small", k_decaps_small<K, ETA1, DU, DV, HC, JR>, n, WAVE * SMALL_WAVES, st, n, dk, c, Kout, sts, ws.A, ws.prf, ws.r, ws.m, ws.Kp, ws.Kbar, rate)
+#define MLKEM_DS(HC, JR) launch("k_decaps_small", k_decaps_small<K, ETA1, DU, DV, HC, JR>, (HC) ? 2 * n : n, WAVE * SMALL_WAVES, st, n, dk, c, Kout, sts, ws.A, ws.prf, ws.r, ws.m, ws.Kp, ws.Kbar, rate)
         if (hash_check && !ws.fips) MLKEM_DS(true, 168);
         else if (!ws.fips) MLKEM_DS(false, 168);
         else if (hash_check) MLKEM_DS(true, 136);

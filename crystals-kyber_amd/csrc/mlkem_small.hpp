@@ -10,8 +10,8 @@
 //   k_encaps_small  stage 1: wave 0: h = H(ek), (K, r) = G(m || h)        | waves 1..: A-hat^T = SampleNTT(rho || j || i)
 //                   stage 2: all waves: PRF(r, n), n = 0..2k
 //                   stage 3: wave 0: K-PKE.Encrypt                                            (ml_kem.c:1093-1130, :776-936)
-//   k_decaps_small  stage 1: wave 0: m' = K-PKE.Decrypt, (K', r') = G(m' || h) | wave 1: Kbar = J(z || c)
-//                            wave 2: status = H(dk.ek) == dk.h ? 0 : -5        | waves 3..: A-hat^T
+//   k_decaps_small  stage 1: wave 0: m' = K-PKE.Decrypt, (K', r') = G(m' || h) | wave 1: Kbar = J(z || c) | waves 2..: A-hat^T
+//                            (status = H(dk.ek) == dk.h ? 0 : -5 in a workgroup of its own: nothing else waits for that chain)
 //                   stage 2: PRF(r', n) ; stage 3: wave 0: c' = Encrypt, K = c == c' ? K' : Kbar   (ml_kem.c:1310-1359, :1136-1225)
 //   k_keygen_small  stage 1: wave 0: (rho, sigma) = G(d || k) ; stage 2: all waves: A-hat and the 2k PRF rows
 //                   stage 3: wave 0: K-PKE.KeyGen, then H(ek) and the dk tail                 (ml_kem.c:1034-1084, :651-769)
@@ -199,10 +199,15 @@ k_decaps_small(size_t n, const uint8_t* __restrict__ dk, const uint8_t* __restri
     __shared__ K2Lds<K + 1> xl;
     __shared__ uint32_t sq[SMALL_WAVES][XOF_LDS_WORDS];
     constexpr unsigned EK = 384 * K + 32, DK = 768 * K + 96, PS = (ETA1 == 3) ? 192 : 128, CLEN = 32 * (DU * K + DV);
-    constexpr int FIRST_XOF = HASH_CHECK ? 3 : 2;    // waves 0 .. FIRST_XOF - 1 run the serial roles
+    constexpr int FIRST_XOF = 2;                     // waves 0, 1 run the serial roles
     const int wv = wave_id();
-    const size_t item = blockIdx.x;
-    if (item >= n) return;
+    // KEM_Decaps' check of the stored H(ek) (9 permutations at k = 3: the longest chain of the operation, and nothing but the
+    // status depends on it) runs in workgroups of its own, one live wave each.  They are blocks [0, n): dispatched first, they
+    // shrink to one wave at once, and the eight-wave workgroup of the item still fits the same CU beside it (a check workgroup
+    // dispatched AFTER the main ones would wait for a whole CU's worth of registers, i.e. for a main workgroup to finish)
+    const bool check_block = HASH_CHECK && blockIdx.x < n;
+    const size_t item = HASH_CHECK && !check_block ? blockIdx.x - n : blockIdx.x;
+    if (item >= n || (check_block && wv != 0)) return;
     const uint8_t* my_dk = dk + item * DK;
     const uint8_t* my_c = c + item * CLEN;
     uint16_t* my_A = A + item * (size_t)(K * K * 256);
@@ -212,6 +217,17 @@ k_decaps_small(size_t n, const uint8_t* __restrict__ dk, const uint8_t* __restri
     wk_lane_init(cst);
     const int i = wk_index();
     const bool prim = wk_primary();
+    if (check_block) {
+        WkState a;
+        wk_H(a, cst, my_dk + 384 * K, EK);
+        uint2 h;
+        h.x = 0; h.y = 0;
+        if (prim && i < 4) h = reinterpret_cast<const uint2*>(my_dk + 768 * K + 32)[i];
+        const bool differ = prim && i < 4 && (h.x != a.lo || h.y != a.hi);
+        const bool bad = __ballot(differ) != 0;
+        if (lane_id() == 0 && status) status[item] = bad ? -5 : 0;
+        return;
+    }
     if (wv == 0) {                                   // m' = K-PKE.Decrypt(dk_pke, c) ; (K', r') = G(m' || h)
         decrypt4_body<K, DU, DV>(0, 1, my_dk, (size_t)DK, my_c, my_m);
         wave_global_fence();
@@ -234,15 +250,6 @@ k_decaps_small(size_t n, const uint8_t* __restrict__ dk, const uint8_t* __restri
         uint2 o;
         o.x = a.lo; o.y = a.hi;
         if (prim && i < 4) reinterpret_cast<uint2*>(my_Kbar)[i] = o;
-    } else if (HASH_CHECK && wv == 2) {              // KEM_Decaps' check of the stored H(ek)
-        WkState a;
-        wk_H(a, cst, my_dk + 384 * K, EK);
-        uint2 h;
-        h.x = 0; h.y = 0;
-        if (prim && i < 4) h = reinterpret_cast<const uint2*>(my_dk + 768 * K + 32)[i];
-        const bool differ = prim && i < 4 && (h.x != a.lo || h.y != a.hi);
-        const bool bad = __ballot(differ) != 0;
-        if (lane_id() == 0 && status) status[item] = bad ? -5 : 0;
     } else {                                         // A-hat^T of the re-encryption (rho sits in dk.ek)
         for (int s = wv - FIRST_XOF; s < K * K; s += SMALL_WAVES - FIRST_XOF)
             wk_sample_ntt(cst, my_dk + 768 * K, (unsigned)(s / K), (unsigned)(s % K), my_A + s * 256, sq[wv]);
