@@ -4,7 +4,7 @@
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 [ -n "$1" ] && export MLKEM_LIB_PATH=$ROOT/$1
 cd $ROOT
-for lg in 6 10 12 14 16 18 20; do
+for lg in 0 6 8 10 12 14 16 18 20; do
   n=$((1 << lg)); steps=$(( lg < 16 ? 200 : 40 ))
   timeout -k 10 200 python3 bench.py --batch $n --steps $steps --warmup 5 --no-cpu --no-also 2>/dev/null | python3 -c "
 import json,sys

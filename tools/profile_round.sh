@@ -7,8 +7,11 @@
 #   the default bench line, the two-rank rehearsal (torch.distributed.run, per_gpu) and the in-process 8-member line;
 #   the host-pointer call latency, the PCIe-inclusive streaming rate and the batch-size sweep.
 # Output: gpurun_out/prof_<tag>/.   The program after `--` is python3 itself (no env / bash -c hop under the profiler).
+# Usage: tools/profile_round.sh <tag> [lines|prof|all]   (two gpurun calls of <= 20 minutes: `lines` = bench lines, sweeps, energy,
+#        test tier; `prof` = the rocprofv3 passes)
 set -u
 TAG=${1:-r04}
+PART=${2:-all}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
@@ -23,6 +26,7 @@ run() {   # name, rocprof args..., -- bench args
 cd "$ROOT"
 rm -f "$OUT/source_id.txt"
 python3 -c "import bench; print(bench.source_id())" > "$OUT/source_id.txt"   # refresh_profiles.sh checks it against the tree it stamps
+if [ "$PART" != "prof" ]; then
 echo "== bench lines" >&2
 timeout -k 10 400 python3 bench.py > "$OUT/bench_default.json" 2> "$OUT/bench_default.err" || { echo "FAILED default bench" >&2; exit 1; }
 for wl in kem512 kem768_shared; do
@@ -36,6 +40,14 @@ timeout -k 10 400 python3 bench.py --inproc --gpus 8 > "$OUT/inproc8.json" 2> "$
 timeout -k 10 200 python3 tools/host_latency.py 2>/dev/null > "$OUT/host_latency.txt" || { echo "FAILED host_latency" >&2; exit 1; }
 timeout -k 10 400 python3 tools/stream_bench.py 2>/dev/null | grep '^{' | tail -1 > "$OUT/stream_bench.json" || { echo "FAILED stream_bench" >&2; exit 1; }
 timeout -k 10 400 bash tools/batch_sweep.sh > "$OUT/batch_sweep.txt" 2>/dev/null || { echo "FAILED batch_sweep" >&2; exit 1; }
+# round 4: small calls (one workgroup per item against the batch path), KeyGen latency, the wave-wide Keccak, energy by kernel family
+timeout -k 10 400 bash tools/small_sweep.sh > "$OUT/small_sweep.txt" 2>/dev/null || { echo "FAILED small_sweep" >&2; exit 1; }
+timeout -k 10 100 python3 tools/keygen_latency.py 2>/dev/null | grep keygen > "$OUT/keygen_latency.txt" || { echo "FAILED keygen_latency" >&2; exit 1; }
+timeout -k 10 100 ./tools/keccak_wave_ubench.bin > "$OUT/keccak_wave_ubench.txt" 2>&1 || { echo "FAILED keccak_wave_ubench" >&2; exit 1; }
+timeout -k 10 300 python3 tools/energy_probe.py 2>/dev/null > "$OUT/energy.txt" || { echo "FAILED energy_probe" >&2; exit 1; }
+timeout -k 10 600 python3 -m pytest tests -m gpu -q 2>&1 | tail -3 > "$OUT/gpu_tier.log" || { echo "FAILED gpu tier" >&2; cat "$OUT/gpu_tier.log" >&2; exit 1; }
+fi
+[ "$PART" = "lines" ] && { ls "$OUT"; exit 0; }
 cd /tmp
 for wl in kem768 ntt kem1024; do
     run kt_$wl --kernel-trace --stats --output-format csv -d "$OUT/kt_$wl" -o $wl -- python3 "$ROOT/bench.py" --workload $wl --no-cpu --no-also || exit 1
@@ -48,5 +60,6 @@ for wl in kem768 ntt kem1024; do
     run sq_$wl --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_LDS SQ_INSTS_SALU GRBM_GUI_ACTIVE \
         --kernel-trace --output-format csv -d "$OUT/sq_$wl" -o $wl -- python3 "$ROOT/bench.py" --workload $wl --no-cpu --no-also --steps 3 --warmup 1 || exit 1
 done
+find "$OUT" -name '*_kernel_trace.csv' -delete     # the per-dispatch traces are not used (stats + counter_collection are) and would not fit the 64 MiB that travel back
 find "$OUT" -name '*.csv' | sed "s|$ROOT/||" | sort
 du -sh "$OUT"

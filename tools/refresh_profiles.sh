@@ -30,6 +30,13 @@ cp $D/inproc8.json profiles/${T}_inproc8.json
 cp $D/host_latency.txt profiles/${T}_host_latency.txt
 cp $D/stream_bench.json profiles/${T}_stream_bench.json
 cp $D/batch_sweep.txt profiles/${T}_batch_sweep_head.txt
+cp $D/small_sweep.txt profiles/${T}_small_sweep.txt
+cp $D/keygen_latency.txt profiles/${T}_keygen_latency.txt
+cp $D/keccak_wave_ubench.txt profiles/${T}_keccak_wave_ubench.txt
+cp $D/energy.txt profiles/${T}_energy.txt
+cp $D/gpu_tier.log profiles/${T}_gpu_tier.log
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -S --cuda-device-only -o /tmp/capi_floor.s crystals-kyber_amd/csrc/mlkem_capi.hip 2>/dev/null && \
+  python tools/isa_floor.py /tmp/capi_floor.s --out profiles/${T}_isa_floor.json > /dev/null || exit 1
 python - $T <<'P'
 import json, sys, bench
 t = sys.argv[1]
