@@ -114,8 +114,9 @@ struct Workspace {
     size_t hcap = 0;   // h-chunk capacity (items) of the 32-byte arrays
     size_t wide_max = 2048;   // calls of at most this many items hash with one sponge per HALF-WAVE (mlkem_wkeccak.hpp: faster
                               // up to 2048 items, slower from 4096, profiles/r03_batch_sweep.txt); env MLKEM_WIDE_HASH_ITEMS
-    size_t small_max = 256;   // calls of at most this many items run as ONE launch, one workgroup per item (mlkem_small.hpp);
-                              // env MLKEM_SMALL_ITEMS (0: never)
+    size_t small_max = 512;   // calls of at most this many items run as ONE launch, one workgroup per item (mlkem_small.hpp): one
+                              // workgroup fits a CU, two rounds of 256 still beat the batch path (0.166 against 0.181 ms per pair
+                              // at 512 items, 0.242 against 0.193 at 768: profiles/r04_small_sweep.txt); env MLKEM_SMALL_ITEMS (0: never)
     // measurement aid (mlkem_ctx_debug_stages, tools/energy_probe.py): which kernel families the batch path launches; the
     // outputs of a call with stages missing are meaningless.  1 = hash kernels, 2 = sampler, 4 = K-PKE.Encrypt / KeyGen, 8 = Decrypt
     unsigned stages = 15;

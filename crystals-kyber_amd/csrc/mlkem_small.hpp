@@ -97,6 +97,7 @@ __device__ __forceinline__ void wk_sample_ntt(const WkLane& c, const uint8_t* rh
 template <int QB = KQ, int CAP = SAMPLE_CAP>
 __global__ void __launch_bounds__(WAVE) k_sample_ntt_w(size_t n, const uint8_t* __restrict__ seeds34, uint16_t* __restrict__ out) {
     __shared__ uint32_t sq[XOF_LDS_WORDS];
+    __shared__ uint2 rc_table[WK_RC_ENTRIES];
     const size_t g = blockIdx.x;
     if (g >= n) return;
     const uint8_t* sp = seeds34 + g * 34;
@@ -109,7 +110,7 @@ __global__ void __launch_bounds__(WAVE) k_sample_ntt_w(size_t n, const uint8_t* 
         seed.y = (uint32_t)b[4] | ((uint32_t)b[5] << 8) | ((uint32_t)b[6] << 16) | ((uint32_t)b[7] << 24);
     }
     WkLane c;
-    wk_lane_init(c);
+    wk_lane_init(c, rc_table);
     wk_sample_ntt_seed<QB, CAP>(c, seed, sp[32], sp[33], out + g * 256, sq);
 }
 
@@ -154,6 +155,7 @@ k_encaps_small(size_t n, const uint8_t* __restrict__ ek, const uint8_t* __restri
                int32_t* __restrict__ mod_status, uint16_t* A, uint8_t* prf, uint8_t* r_ws, int prf_rate) {
     __shared__ K2Lds<K + 1> xl;
     __shared__ uint32_t sq[SMALL_WAVES][XOF_LDS_WORDS];
+    __shared__ uint2 rc_tables[SMALL_WAVES][WK_RC_ENTRIES];
     constexpr unsigned EK = 384 * K + 32, PS = (ETA1 == 3) ? 192 : 128, CLEN = 32 * (DU * K + DV);
     const int wv = wave_id();
     const size_t item = blockIdx.x;
@@ -163,7 +165,7 @@ k_encaps_small(size_t n, const uint8_t* __restrict__ ek, const uint8_t* __restri
     uint8_t* my_prf = prf + item * (size_t)((2 * K + 1) * PS);
     uint8_t* my_r = r_ws + item * 32;
     WkLane cst;
-    wk_lane_init(cst);
+    wk_lane_init(cst, rc_tables[wave_id()]);
     if (wv == 0) {                                   // h = H(ek) ; (K, r) = G(m || h)
         const int i = wk_index();
         WkState a;
@@ -198,6 +200,7 @@ k_decaps_small(size_t n, const uint8_t* __restrict__ dk, const uint8_t* __restri
                uint16_t* A, uint8_t* prf, uint8_t* r_ws, uint8_t* m_ws, uint8_t* Kp_ws, uint8_t* Kbar_ws, int prf_rate) {
     __shared__ K2Lds<K + 1> xl;
     __shared__ uint32_t sq[SMALL_WAVES][XOF_LDS_WORDS];
+    __shared__ uint2 rc_tables[SMALL_WAVES][WK_RC_ENTRIES];
     constexpr unsigned EK = 384 * K + 32, DK = 768 * K + 96, PS = (ETA1 == 3) ? 192 : 128, CLEN = 32 * (DU * K + DV);
     constexpr int FIRST_XOF = 2;                     // waves 0, 1 run the serial roles
     const int wv = wave_id();
@@ -214,7 +217,7 @@ k_decaps_small(size_t n, const uint8_t* __restrict__ dk, const uint8_t* __restri
     uint8_t* my_prf = prf + item * (size_t)((2 * K + 1) * PS);
     uint8_t *my_r = r_ws + item * 32, *my_m = m_ws + item * 32, *my_Kp = Kp_ws + item * 32, *my_Kbar = Kbar_ws + item * 32;
     WkLane cst;
-    wk_lane_init(cst);
+    wk_lane_init(cst, rc_tables[wave_id()]);
     const int i = wk_index();
     const bool prim = wk_primary();
     if (check_block) {
@@ -272,6 +275,7 @@ k_keygen_small(size_t n, const uint8_t* __restrict__ d, const uint8_t* __restric
                uint8_t* rho_ws, uint8_t* sigma_ws, int prf_rate) {
     __shared__ K2Lds<K> xl;
     __shared__ uint32_t sq[SMALL_WAVES][XOF_LDS_WORDS];
+    __shared__ uint2 rc_tables[SMALL_WAVES][WK_RC_ENTRIES];
     constexpr unsigned EK = 384 * K + 32, DK = KEM_DK ? 768 * K + 96 : 384 * K, PS = (ETA1 == 3) ? 192 : 128;
     const int wv = wave_id();
     const size_t item = blockIdx.x;
@@ -281,7 +285,7 @@ k_keygen_small(size_t n, const uint8_t* __restrict__ d, const uint8_t* __restric
     uint8_t* my_prf = prf + item * (size_t)(2 * K * PS);
     uint8_t *my_rho = rho_ws + item * 32, *my_sigma = sigma_ws + item * 32;
     WkLane cst;
-    wk_lane_init(cst);
+    wk_lane_init(cst, rc_tables[wave_id()]);
     const int i = wk_index();
     const bool prim = wk_primary();
     if (wv == 0) {                                   // (rho, sigma) = G(d || k)   (ml_kem.c:674-681)

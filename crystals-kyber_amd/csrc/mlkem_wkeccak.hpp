@@ -14,9 +14,10 @@
 //   rho     a per-lane 64-bit rotate (two v_alignbit with the lane's own shift, halves pre-swapped for offsets >= 32);
 //   pi+chi  lane (x', y') fetches the rotated lanes that pi maps to (x', y'), (x' + 1, y'), (x' + 2, y') with six ds_bpermute_b32
 //           -- the round's only LDS trip; copies fetch what their primary fetches, which is what keeps them valid;
-//   iota    the lanes holding (0, 0).
-// Round 3's form (one sponge per half-wave, 18 ds_bpermute per round in three dependent groups) ran 5.3 us per permutation
-// for a lone wave; tools/keccak_wave_ubench.hip measures both (profiles/r04_keccak_wave_ubench.txt).
+//   iota    the lanes holding (0, 0), from a 200-byte table of the wave in LDS.
+// 24 VALU + 7 DS instructions per round, 2.9 us per permutation of a lone wave.  Round 3's form (one sponge per half-wave, 18
+// ds_bpermute per round in three dependent groups) ran 4.8; tools/keccak_wave_ubench.hip measures all forms
+// (profiles/r04_keccak_wave_ubench.txt).
 // Message bytes map 1:1: Keccak lane i = x + 5 y owns bytes [8 i, 8 i + 8) of every rate block, so absorbing is one 8-byte
 // load per lane and block.  All message lengths on this path are multiples of 8 (ek, z || c, m || h) or fit one block.
 // Follows sha3.c:15-216 (permutation), :257-330 (sponge) of the reference.
@@ -84,14 +85,30 @@ __device__ __forceinline__ bool wk_primary() {
 }
 
 // per-lane constants of the round
+constexpr int WK_RC_ENTRIES = 25;   // the wave's table in LDS: the 24 round constants and a zero entry
 struct WkLane {
     uint32_t src[3];      // byte addresses (lane * 4) of the pi sources of (x, y), (x + 1, y), (x + 2, y)
     uint32_t sh;          // v_alignbit shift of rho
     uint32_t keep;        // all-ones in the lanes that carry state
     bool swp;             // rho offset >= 32 (or 0): halves swapped before the shift
     bool is00;            // holds Keccak lane (0, 0): iota
+    const uint2* rc;      // iota: the lanes holding (0, 0) read entry `round` of the wave's table, all others its zero entry --
+                          // one ds_read_b64 per round instead of two scalar loads + two selects
 };
-__device__ __forceinline__ void wk_lane_init(WkLane& c) {
+// `rc_table`: WK_RC_ENTRIES entries of LDS owned by the calling wave (filled here)
+__device__ __forceinline__ void wk_lane_init(WkLane& c, uint2* rc_table) {
+    const unsigned l = (unsigned)lane_id();
+    if (l < 24u) {
+        uint2 v;
+        v.x = KECCAK_RC[2 * l]; v.y = KECCAK_RC[2 * l + 1];
+        rc_table[l] = v;
+    } else if (l == 24u) {
+        uint2 v;
+        v.x = 0; v.y = 0;
+        rc_table[24] = v;
+    }
+    wave_lds_fence();
+    c.rc = rc_table;
     const int i = wk_index();
     const int ii = i < 0 ? 0 : i;                       // idle lanes run lane 0's constants; `keep` zeroes what they compute
     const int x = ii % 5, y = ii / 5;
@@ -117,9 +134,11 @@ __device__ __forceinline__ void wk_canon(WkState& a, const WkLane& c) {
 }
 
 __device__ __forceinline__ void wk_permute(WkState& a, const WkLane& c) {
+    const uint2* rcp = c.is00 ? c.rc : c.rc + 24;
 #pragma unroll 1
     for (int round = 0; round < 24; round++) {
-        const uint32_t rcl = KECCAK_RC[2 * round], rch = KECCAK_RC[2 * round + 1];   // scalar loads, in flight during the round
+        const uint2 rc = *rcp;                  // issued first: long since there when iota needs it
+        rcp += c.is00 ? 1 : 0;
         // theta: column parity C[x] in every lane of the wave
         uint32_t tl = a.lo ^ wk_row_ror8(a.lo), th = a.hi ^ wk_row_ror8(a.hi);   // rows y = 2r, 2r + 1 folded, both 8-lane groups
         wk_swap32(tl, th);                  // tl = [lo rows 0 1 | hi rows 0 1], th = [lo rows 2 3 | hi rows 2 3]
@@ -127,9 +146,22 @@ __device__ __forceinline__ void wk_permute(WkState& a, const WkLane& c) {
         wk_swap16(u, v);
         uint32_t cl = u ^ v, ch = cl;       // lanes 0..31: C.lo, lanes 32..63: C.hi
         wk_swap32(cl, ch);                  // cl = C.lo everywhere, ch = C.hi everywhere
-        // D[x] = C[x - 1] ^ rotl(C[x + 1], 1), applied
+        // D[x] = C[x - 1] ^ rotl(C[x + 1], 1), applied: two v_xor_b32_dpp per word (left to itself the compiler moves one
+        // operand with v_mov_b32_dpp first: three instructions per word)
         const uint32_t rl = __builtin_amdgcn_alignbit(cl, ch, 31), rh = __builtin_amdgcn_alignbit(ch, cl, 31);
-        const uint32_t al = (a.lo ^ wk_row_shr1(cl)) ^ wk_row_shl1(rl), ah = (a.hi ^ wk_row_shr1(ch)) ^ wk_row_shl1(rh);
+        uint32_t al, ah;
+#ifdef MLKEM_EMU
+        al = (a.lo ^ wk_row_shr1(cl)) ^ wk_row_shl1(rl);
+        ah = (a.hi ^ wk_row_shr1(ch)) ^ wk_row_shl1(rh);
+#else
+        // (DPP hazards: cl / ch were written at least two instructions -- the two v_alignbit above, whose results this block
+        // needs -- before the first DPP read, rl / rh at least two before theirs)
+        asm volatile("v_xor_b32_dpp %0, %2, %4 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                     "v_xor_b32_dpp %1, %3, %5 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                     "v_xor_b32_dpp %0, %6, %0 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                     "v_xor_b32_dpp %1, %7, %1 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+                     : "=&v"(al), "=&v"(ah) : "v"(cl), "v"(ch), "v"(a.lo), "v"(a.hi), "v"(rl), "v"(rh));
+#endif
         // rho (this lane's offset)
         const uint32_t a0 = c.swp ? ah : al, a1 = c.swp ? al : ah;
         const uint32_t bl = __builtin_amdgcn_alignbit(a0, a1, c.sh), bh = __builtin_amdgcn_alignbit(a1, a0, c.sh);
@@ -137,8 +169,8 @@ __device__ __forceinline__ void wk_permute(WkState& a, const WkLane& c) {
         const uint32_t b0l = wk_fetch(c.src[0], bl), b1l = wk_fetch(c.src[1], bl), b2l = wk_fetch(c.src[2], bl);
         const uint32_t b0h = wk_fetch(c.src[0], bh), b1h = wk_fetch(c.src[1], bh), b2h = wk_fetch(c.src[2], bh);
         // iota in the lanes holding (0, 0), zero in the idle lanes: (chi & keep) ^ rc as one v_bitop3
-        a.lo = __builtin_amdgcn_bitop3_b32(MLKEM_CHI(b0l, b1l, b2l), c.keep, c.is00 ? rcl : 0u, 0x6A);
-        a.hi = __builtin_amdgcn_bitop3_b32(MLKEM_CHI(b0h, b1h, b2h), c.keep, c.is00 ? rch : 0u, 0x6A);
+        a.lo = __builtin_amdgcn_bitop3_b32(MLKEM_CHI(b0l, b1l, b2l), c.keep, rc.x, 0x6A);
+        a.hi = __builtin_amdgcn_bitop3_b32(MLKEM_CHI(b0h, b1h, b2h), c.keep, rc.y, 0x6A);
     }
 }
 
@@ -195,9 +227,10 @@ __global__ void __launch_bounds__(WAVE) k_hash_encaps_w(size_t n, const uint8_t*
     constexpr unsigned EK = 384 * K + 32;
     const size_t item = blockIdx.x;
     if (item >= n) return;
+    __shared__ uint2 rc_table[WK_RC_ENTRIES];
     const int i = wk_index();
     WkLane c;
-    wk_lane_init(c);
+    wk_lane_init(c, rc_table);
     WkState a;
     wk_absorb<136, 0x06>(a, c, ek + item * EK, EK, ek, EK);
     uint2 mv;
@@ -219,9 +252,10 @@ __global__ void __launch_bounds__(WAVE) k_hash_keygen_fin_w(size_t n, const uint
     constexpr unsigned EK = 384 * K + 32, DK = 768 * K + 96;
     const size_t item = blockIdx.x;
     if (item >= n) return;
+    __shared__ uint2 rc_table[WK_RC_ENTRIES];
     const int i = wk_index();
     WkLane c;
-    wk_lane_init(c);
+    wk_lane_init(c, rc_table);
     WkState a;
     wk_absorb<136, 0x06>(a, c, ek + item * EK, EK, ek, EK);
     uint2 o;
@@ -247,8 +281,9 @@ __global__ void __launch_bounds__(WAVE) k_hash_decaps_w(size_t n, const uint8_t*
     const int i = wk_index();
     const bool prim = wk_primary();
     const uint8_t* my_dk = dk + item * dk_stride;
+    __shared__ uint2 rc_table[WK_RC_ENTRIES];
     WkLane cst;
-    wk_lane_init(cst);
+    wk_lane_init(cst, rc_table);
     WkState a;
     if (check_role) {
         wk_absorb<136, 0x06>(a, cst, my_dk + 384 * K, EK, my_dk, EK);

@@ -378,9 +378,9 @@ def test_single_chunk_calls_keep_their_results_with_and_without_the_side_stream(
     e.close()
 
 
-@pytest.mark.parametrize("n", (1, 2, 255, 256, 257, 2047, 2048, 2049))
+@pytest.mark.parametrize("n", (1, 2, 256, 257, 511, 512, 513, 2047, 2048, 2049))
 def test_default_path_switches_at_their_boundaries(pkg, torch, oracle, n):
-    """The sizes either side of Workspace::small_max (256: one workgroup per item | batch kernels) and Workspace::wide_max
+    """The sizes either side of Workspace::small_max (512: one workgroup per item, two rounds of 256 | batch kernels; 256 | 257: the end of the first round) and Workspace::wide_max
     (2048: one sponge per wave + direct sampler | lane-sliced hashes + three-block sampler), default environment, one chunk
     (chunk_items 4096): ML-KEM-768 keygen -> encaps -> decaps with tampered ciphertexts and one corrupted stored hash."""
     pset = 768

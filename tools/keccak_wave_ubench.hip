@@ -1,8 +1,9 @@
 // tools/keccak_wave_ubench.hip -- measurement aid: latency of ONE Keccak-f[1600] for a lone wave in three forms
 //   lane   : lane-sliced (one sponge per SIMD lane, mlkem_device.hpp: keccak_f1600)
 //   half   : one sponge per half-wave, 18 ds_bpermute per round in three dependent groups (round-3 form, kept here as `hw_*`)
-//   wave   : one sponge per wave, theta by DPP + v_permlane swaps, ONE dependent group of 6 ds_bpermute per round
-//            (mlkem_wkeccak.hpp: wk_permute)
+//   wave   : one sponge per wave, theta by DPP + v_permlane swaps, ONE dependent group of 6 ds_bpermute per round, iota's
+//            constant from an LDS table (mlkem_wkeccak.hpp: wk_permute; the first form of the round -- scalar loads + selects for
+//            iota, three instructions per word for D -- ran 3.43 us)
 // and a correctness check of the wave forms against the lane-sliced permutation on random states.
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -69,8 +70,9 @@ __global__ void __launch_bounds__(64) k_half(uint32_t* out, int perms) {
     out[blockIdx.x * 64 + threadIdx.x] = lo ^ hi;
 }
 __global__ void __launch_bounds__(64) k_wave(uint32_t* out, int perms) {
+    __shared__ uint2 rc_table[WK_RC_ENTRIES];
     WkLane c;
-    wk_lane_init(c);
+    wk_lane_init(c, rc_table);
     WkState a;
     a.lo = threadIdx.x * 2654435761u; a.hi = blockIdx.x * 40503u + threadIdx.x;
     wk_canon(a, c);
@@ -79,8 +81,9 @@ __global__ void __launch_bounds__(64) k_wave(uint32_t* out, int perms) {
 }
 // correctness: state words in[50] (lo/hi of Keccak lane i at in[2i], in[2i+1]) -> out[50] after `perms` permutations
 __global__ void __launch_bounds__(64) k_wave_check(const uint32_t* in, uint32_t* out, int perms) {
+    __shared__ uint2 rc_table[WK_RC_ENTRIES];
     WkLane c;
-    wk_lane_init(c);
+    wk_lane_init(c, rc_table);
     WkState a;
     const int i = wk_index();   // Keccak lane x + 5 y this SIMD lane holds, or -1
     a.lo = i >= 0 ? in[2 * i] : 0u;
@@ -98,6 +101,7 @@ __global__ void __launch_bounds__(64) k_lane_check(const uint32_t* in, uint32_t*
         for (int i = 0; i < 25; i++) { out[2 * i] = s.lo[i]; out[2 * i + 1] = s.hi[i]; }
     }
 }
+
 
 template <class F>
 static float time_ms(F launch) {
