@@ -370,15 +370,15 @@ __device__ __forceinline__ void k2_compress4(const v2f (&x)[4], unsigned (&c)[8]
 // value of lane `lane ^ 1` (the other lane of an even / odd pair) / of the previous lane of the quad (lane 0 of a quad: itself)
 __device__ __forceinline__ uint32_t k2_swap1(uint32_t v) {
 #ifdef MLKEM_EMU
-    return (uint32_t)__shfl((int)v, (int)((threadIdx.x & 63) ^ 1));
+    return (uint32_t)emu_quad_shfl((int)v, (int)((threadIdx.x & 3) ^ 1));
 #else
     return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true);   // quad_perm:[1,0,3,2]
 #endif
 }
 __device__ __forceinline__ uint32_t k2_prev_in_quad(uint32_t v) {
 #ifdef MLKEM_EMU
-    const int l = (int)(threadIdx.x & 63);
-    return (uint32_t)__shfl((int)v, (l & 3) ? l - 1 : l);
+    const int l = (int)(threadIdx.x & 3);
+    return (uint32_t)emu_quad_shfl((int)v, l ? l - 1 : l);
 #else
     return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x90, 0xF, 0xF, true);   // quad_perm:[0,0,1,2]
 #endif
@@ -629,6 +629,133 @@ encrypt2_body(float2 (*xch)[2][128], size_t item0, size_t n, const uint8_t* __re
         }
     }
 }
+// ------------------------------------------------------------------------------------------------
+// encrypt1_body — K-PKE.Encrypt of ONE item on one wave: the two half-waves share the item instead of carrying one each.
+// Used by the one-workgroup-per-item kernels (mlkem_small.hpp), where a wave's second half would otherwise redo the first
+// one's item.  Both halves run the k forward transforms (each needs all of y-hat in its registers); the k + 1 output rows
+// -- u[0..k-1] and v -- are dealt out alternately: half h computes rows 2 i + h, i.e. the base-case products, inverse transforms,
+// Compress / ByteEncode (or the compare) of ceil((k + 1) / 2) rows instead of k + 1.  Where the two halves' rows differ in kind
+// (u: matrix row, d_u ; v: t-hat row, message bits, d_v) the wave runs both code paths one after the other under the halves'
+// EXEC masks; for even k the last v row is computed by both halves and stored by the lower one.
+// Pointers address the item itself (no item index); `xch` = K2Lds<(K + 2) / 2 or more>::xch of the wave.
+// ------------------------------------------------------------------------------------------------
+template <int K, int ETA1, int DU, int DV, bool COMPARE>
+__device__ __forceinline__ void
+encrypt1_body(float2 (*xch)[2][128], const uint8_t* __restrict__ ek, const uint8_t* __restrict__ msg, const uint16_t* __restrict__ A,
+              const uint8_t* __restrict__ prf, uint8_t* __restrict__ c_out, const uint8_t* __restrict__ c_in, const uint8_t* __restrict__ Kp,
+              const uint8_t* __restrict__ Kbar, uint8_t* __restrict__ Kout, int32_t* __restrict__ mod_status) {
+    const int l = lane_id(), h = l >> 5, t = l & 31, nb = k2_blk(t);
+    constexpr unsigned PS = (ETA1 == 3) ? 192 : 128;
+    constexpr int NG = K + 1, NL = (NG + 1) / 2;       // rows in all, rows per half
+    // kind of local row i: 0 = both halves a matrix row ; 1 = lower half a matrix row, upper half v ; 2 = v in both halves (even k)
+    auto kind = [](int i) constexpr { return 2 * i + 1 < K ? 0 : (2 * i < K ? 1 : 2); };
+
+    K2CbdRaw<ETA1> raw_y[K];
+#pragma unroll
+    for (int b = 0; b < K; b++) k2_cbd_load_la<ETA1>(prf + b * PS, t, raw_y[b]);
+    uint4 a_all[NL][K];
+    uint32_t raw_e[NL];
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+        const int a = kind(i) == 2 ? K : 2 * i + h;    // this half's row
+        const bool is_v = kind(i) == 2 || (kind(i) == 1 && h == 1);
+#pragma unroll
+        for (int b = 0; b < K; b++) {
+            if (is_v) {                                // t-hat: ByteEncode_12 pieces
+                const uint32_t* gp = reinterpret_cast<const uint32_t*>(ek + 384 * b) + 3 * nb;
+                a_all[i][b].x = gp[0]; a_all[i][b].y = gp[1]; a_all[i][b].z = gp[2]; a_all[i][b].w = 0u;
+            } else {
+                a_all[i][b] = *reinterpret_cast<const uint4*>(A + (a * K + b) * 256 + 8 * nb);
+            }
+        }
+        raw_e[i] = k2_cbd_load_nat2(prf + (K + a) * PS, nb);
+    }
+    const unsigned mb = msg[nb];                       // the lane's 8 message bits
+
+    v2f yh[K][4];
+    float yg[K][4];
+    {
+        K2Tw tw;
+        k2_twiddles_fwd(tw, t);
+#pragma unroll
+        for (int b = 0; b < K; b++) k2_cbd_eval<ETA1>(raw_y[b], yh[b]);
+        k2_ntt<K>(yh, xch, h, t, tw);
+#pragma unroll
+        for (int b = 0; b < K; b++) {
+            k2_fred_n<4>(yh[b]);
+            k2_gamma(yh[b], tw.d0, tw.d1, yg[b]);
+        }
+    }
+    uint32_t diff = 0;
+    bool over = false;
+    v2f acc[NL][4];
+    K2Piece<DU> cu_ref[NL];
+    K2Piece<DV> cv_ref;
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+        const bool is_v = kind(i) == 2 || (kind(i) == 1 && h == 1);
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = splat2(0.f);
+#pragma unroll
+        for (int b = 0; b < K; b++) {
+            v2f av[4];
+            if (is_v) {
+                k2_decode12(a_all[i][b].x, a_all[i][b].y, a_all[i][b].z, av);   // raw 12-bit values (F3)
+#pragma unroll
+                for (int j = 0; j < 4; j++) over = over || (av[j].x >= F_Q) || (av[j].y >= F_Q);
+            } else {
+                k2_unpack16(a_all[i][b], av);
+            }
+            k2_basemul_acc(acc[i], av, yh[b], yg[b]);
+        }
+    }
+    if constexpr (COMPARE) {
+#pragma unroll
+        for (int i = 0; i < NL; i++) {
+            const int a = kind(i) == 2 ? K : 2 * i + h;
+            const bool is_v = kind(i) == 2 || (kind(i) == 1 && h == 1);
+            if (is_v) k2_piece_load<DV>(c_in + K * 32 * DU, nb, cv_ref);
+            else k2_piece_load<DU>(c_in + a * 32 * DU, nb, cu_ref[i]);
+        }
+    }
+    {
+        K2Tw twi;
+        k2_twiddles_inv(twi, t);
+        k2_intt<NL>(acc, xch, h, t, twi);
+    }
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+        const int a = kind(i) == 2 ? K : 2 * i + h;
+        const bool is_v = kind(i) == 2 || (kind(i) == 1 && h == 1);
+        const bool store = kind(i) != 2 || h == 0;     // even k: the v row exists in both halves
+        v2f e[4];
+        k2_cbd2_eval8<true>(raw_e[i], e);              // e1 / e2 + 2: the bias leaves in Compress's first FMA
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = acc[i][j] + e[j];
+        if (is_v) {
+#pragma unroll
+            for (int j = 0; j < 4; j++)                // Decompress_1(1) = 1665
+                acc[i][j] = acc[i][j] + v2f{((mb >> (2 * j)) & 1u) ? 1665.0f : 0.0f, ((mb >> (2 * j + 1)) & 1u) ? 1665.0f : 0.0f};
+            diff |= k2_emit<DV, COMPARE, true>(acc[i], nb, COMPARE ? nullptr : c_out + K * 32 * DU, cv_ref, store);
+        } else {
+            diff |= k2_emit<DU, COMPARE, true>(acc[i], nb, COMPARE ? nullptr : c_out + a * 32 * DU, cu_ref[i], store);
+        }
+    }
+    if (mod_status) {
+        const bool bad = __ballot(over) != 0;
+        if (l == 0) mod_status[0] = bad ? -4 : 0;
+    }
+    if constexpr (COMPARE) {
+        // both candidates are read and blended by mask: neither a branch nor an address depends on whether the ciphertext matched
+        const uint32_t reject = __ballot(diff != 0) != 0 ? 0xFFFFFFFFu : 0u;
+        if (l < 8) {
+            const uint32_t kp = reinterpret_cast<const uint32_t*>(Kp)[l];
+            const uint32_t kb = reinterpret_cast<const uint32_t*>(Kbar)[l];
+            reinterpret_cast<uint32_t*>(Kout)[l] = (kp & ~reject) | (kb & reject);
+        }
+    }
+}
+
 template <int K, int ETA1, int DU, int DV, bool COMPARE>
 __global__ void __launch_bounds__(WAVE * KPKE2_WAVES, kpke2_minwaves(K))
 k_encrypt2(size_t n, const uint8_t* __restrict__ ek, size_t ek_stride, const uint8_t* __restrict__ msg, const uint16_t* __restrict__ A,

@@ -6,7 +6,8 @@
 // gap between each.  Here the item's whole operation is one workgroup of SMALL_WAVES wavefronts that run the item's
 // independent sponges SIDE BY SIDE, each on the one-sponge-per-wave Keccak of mlkem_wkeccak.hpp (3.5 us per permutation for a
 // lone wave instead of 8.8 lane-sliced), meet at workgroup barriers, and hand the sampled matrix and the PRF rows to the
-// arithmetic (the same encrypt2_body / keygen2_body / decrypt4_body the batch kernels run) through the call's scratch in HBM:
+// arithmetic (keygen2_body / decrypt4_body as the batch kernels run them; encrypt1_body, where the two half-waves share the item's
+// k + 1 output rows) through the call's scratch in HBM:
 //   k_encaps_small  stage 1: wave 0: h = H(ek), (K, r) = G(m || h)        | waves 1..: A-hat^T = SampleNTT(rho || j || i)
 //                   stage 2: all waves: PRF(r, n), n = 0..2k
 //                   stage 3: wave 0: K-PKE.Encrypt                                            (ml_kem.c:1093-1130, :776-936)
@@ -187,15 +188,15 @@ k_encaps_small(size_t n, const uint8_t* __restrict__ ek, const uint8_t* __restri
         wk_prf(cst, my_r, (unsigned)j, j < K ? (unsigned)ETA1 : 2u, (unsigned)prf_rate, my_prf + j * PS);
     block_barrier();
     if (wv == 0)
-        encrypt2_body<K, ETA1, DU, DV, false>(xl.xch, 0, 1, my_ek, (size_t)EK, m + item * 32, my_A, my_prf, c + item * CLEN, nullptr, nullptr, nullptr,
-                                              nullptr, mod_status ? mod_status + item : nullptr, (size_t)(K * K * 256));
+        encrypt1_body<K, ETA1, DU, DV, false>(xl.xch, my_ek, m + item * 32, my_A, my_prf, c + item * CLEN, nullptr, nullptr, nullptr, nullptr,
+                                              mod_status ? mod_status + item : nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------
 // k_decaps_small — KEM_Decaps / Decaps_internal (ml_kem.c:1310-1359, :1136-1225), one workgroup per item
 // ------------------------------------------------------------------------------------------------
 template <int K, int ETA1, int DU, int DV, bool HASH_CHECK, int JRATE>
-__global__ void __launch_bounds__(WAVE * SMALL_WAVES)
+__global__ void __launch_bounds__(WAVE * SMALL_WAVES)   // (forced to 128 VGPRs -- two workgroups per CU -- k = 3 spills 88 bytes: not done)
 k_decaps_small(size_t n, const uint8_t* __restrict__ dk, const uint8_t* __restrict__ c, uint8_t* __restrict__ Kout, int32_t* __restrict__ status,
                uint16_t* A, uint8_t* prf, uint8_t* r_ws, uint8_t* m_ws, uint8_t* Kp_ws, uint8_t* Kbar_ws, int prf_rate) {
     __shared__ K2Lds<K + 1> xl;
@@ -262,8 +263,7 @@ k_decaps_small(size_t n, const uint8_t* __restrict__ dk, const uint8_t* __restri
         wk_prf(cst, my_r, (unsigned)j, j < K ? (unsigned)ETA1 : 2u, (unsigned)prf_rate, my_prf + j * PS);
     block_barrier();
     if (wv == 0)
-        encrypt2_body<K, ETA1, DU, DV, true>(xl.xch, 0, 1, my_dk + 384 * K, (size_t)DK, my_m, my_A, my_prf, nullptr, my_c, my_Kp, my_Kbar,
-                                             Kout + item * 32, nullptr, (size_t)(K * K * 256));
+        encrypt1_body<K, ETA1, DU, DV, true>(xl.xch, my_dk + 384 * K, my_m, my_A, my_prf, nullptr, my_c, my_Kp, my_Kbar, Kout + item * 32, nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -34,9 +34,12 @@ struct alignas(16) float4 { float x, y, z, w; };
 namespace emu {
 struct WaveCtx {
     pthread_barrier_t bar;
+    pthread_barrier_t qbar[16];   // one per quad of four lanes: DPP quad_perm exchanges, which the device code also issues inside
+    uint64_t qslot[2][64];        // lane-divergent branches (only the lanes of the quad have to arrive)
     uint64_t slot[2][64];   // two exchange buffers used alternately: ONE barrier per cross-lane operation (a lane can run at
                             // most one operation ahead of the slowest lane, and then writes the other buffer)
 };
+static thread_local unsigned qphase = 0;
 static thread_local unsigned xphase = 0;   // every lane of a wave executes the same sequence of cross-lane operations
 static thread_local WaveCtx* wave = nullptr;
 static thread_local pthread_barrier_t* block_bar = nullptr;
@@ -51,6 +54,7 @@ inline void launch(unsigned grid, unsigned block, F body) {
         for (unsigned w = 0; w < nwaves; w++) {
             unsigned lanes = block - 64 * w < 64 ? block - 64 * w : 64;
             pthread_barrier_init(&ctx[w].bar, nullptr, lanes);
+            for (int q = 0; q < 16; q++) pthread_barrier_init(&ctx[w].qbar[q], nullptr, 4);
         }
         pthread_barrier_t bbar;
         pthread_barrier_init(&bbar, nullptr, block);
@@ -62,11 +66,15 @@ inline void launch(unsigned grid, unsigned block, F body) {
                 wave = &ctx[t / 64];
                 block_bar = &bbar;
                 xphase = 0;
+                qphase = 0;
                 body();
             });
         for (auto& x : th) x.join();
         pthread_barrier_destroy(&bbar);
-        for (unsigned w = 0; w < nwaves; w++) pthread_barrier_destroy(&ctx[w].bar);
+        for (unsigned w = 0; w < nwaves; w++) {
+            pthread_barrier_destroy(&ctx[w].bar);
+            for (int q = 0; q < 16; q++) pthread_barrier_destroy(&ctx[w].qbar[q]);
+        }
     }
 }
 }   // namespace emu
@@ -105,6 +113,14 @@ inline int __shfl(int v, int src) {
     slot[l] = (uint64_t)(uint32_t)v;
     emu::wave_barrier();
     return (int)(uint32_t)slot[src & 63];
+}
+// value of lane `src` of the caller's own quad (DPP quad_perm): synchronises the four lanes of the quad only
+inline int emu_quad_shfl(int v, int src) {
+    const int l = threadIdx.x & 63;
+    uint64_t* slot = emu::wave->qslot[emu::qphase++ & 1];
+    slot[l] = (uint64_t)(uint32_t)v;
+    pthread_barrier_wait(&emu::wave->qbar[l >> 2]);
+    return (int)(uint32_t)slot[(l & ~3) | (src & 3)];
 }
 inline int __shfl_xor(int v, int mask) { return __shfl(v, (int)((threadIdx.x & 63) ^ (unsigned)mask)); }
 inline uint32_t atomicOr(uint32_t* p, uint32_t v) { return __atomic_fetch_or(p, v, __ATOMIC_RELAXED); }
