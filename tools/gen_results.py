@@ -175,6 +175,7 @@ def main():
         L.append(sq)
         L.append("")
     for name, title in (("rehearsal_gpus2.json", "`bench.py --gpus 2 --rehearse` under torch.distributed.run (two ranks share the one GPU, gloo barrier)"),
+                        ("rehearsal_gpus4.json", "`bench.py --gpus 4 --rehearse` (four ranks share the one GPU)"),
                         ("inproc8.json", "`bench.py --inproc --gpus 8` (one process, eight members through `mlkem_*_multi_dev`, all on the one GPU)")):
         j = load(name)
         if not j:
@@ -214,7 +215,9 @@ def main():
                 v, k = best(kind)
                 L.append("* streaming %d items, %s buffers: %.3g pairs/s at chunk %s (`profiles/%s_stream_bench.json`)" % (sb["items"], kind, v, k.rsplit("_", 1)[1], TAG))
         L.append("")
-    for name, title in (("small_sweep.txt", "Small calls: one workgroup per item against the batch path (`tools/small_sweep.sh`)"),
+    for name, title in (("soak.txt", "Sustained run (`tools/soak.py`)"),
+                        ("small_kernel_stats.txt", "Small-call kernels under rocprofv3 (`tools/small_profile.sh`)"),
+                        ("small_sweep.txt", "Small calls: one workgroup per item against the batch path (`tools/small_sweep.sh`)"),
                         ("energy.txt", "Energy by kernel family, each looped alone at its 2^20 shapes (`tools/energy_probe.py`)"),
                         ("keccak_wave_ubench.txt", "Keccak-f[1600] of a lone wave: lane-sliced / half-wave (round 3) / wave-wide (`tools/keccak_wave_ubench.hip`)")):
         path = os.path.join(P, "%s_%s" % (TAG, name))
