@@ -33,7 +33,7 @@ ABI_SYMBOLS = (
     "mlkem_compress_encode_dev", "mlkem_decode_decompress_dev",
     "mlkem_prf_dev", "mlkem_hash_dev", "mlkem_keccak_sponge_dev", "mlkem_sha3_pad_bits",
     "mlkem_keygen", "mlkem_encaps", "mlkem_decaps", "mlkem_ntt", "mlkem_intt", "mlkem_keccak_sponge",
-    "mlkem_sample_ntt", "mlkem_sample_cbd",
+    "mlkem_sample_ntt", "mlkem_sample_ntt_retries", "mlkem_sample_ntt_retries_dev", "mlkem_sample_cbd",
     "mlkem_keygen_random", "mlkem_encaps_random",
     "mlkem_cells_to_bytes_dev", "mlkem_bytes_to_cells_dev", "mlkem_keygen_stream", "mlkem_encaps_stream", "mlkem_decaps_stream", "mlkem_stream_release",
     "mlkem_compress_dev", "mlkem_decompress_dev", "mlkem_compress", "mlkem_decompress", "mlkem_sha3_pad_suffix",

@@ -167,11 +167,15 @@ static void narrow_poly(const union integer* f, unsigned short* c) {
     for (int i = 0; i < 256; i++) c[i] = (unsigned short)f[i].t;
 }
 union integer* SampleNTT(union byte* B) {   /* ml_kem.c:189-245 */
-    unsigned char seed[34];
+    unsigned char seed[34], retries = 0;
     unsigned short a[256];
     if (!B) return NULL;
     for (int i = 0; i < 34; i++) seed[i] = (unsigned char)B[i].e;
-    if (engine_failed("SampleNTT()", mlkem_sample_ntt(1, seed, a))) return NULL;
+    if (engine_failed("SampleNTT()", mlkem_sample_ntt_retries(1, seed, a, &retries))) return NULL;
+    /* ml_kem.c:237-242: on exhausting its triples the reference does B[32].e += 1, B[33].e += 1 in the CALLER's buffer and
+     * starts over; the engine reports how often (0 for every real SHAKE stream) and the same 8-bit fields are advanced here */
+    B[32].e += retries;
+    B[33].e += retries;
     return widen_poly(a);
 }
 union integer* SamplePolyCBD(const union byte* B, unsigned int n) {   /* ml_kem.c:253-275 */

@@ -397,11 +397,14 @@ int mlkem_poly_sub_dev(mlkem_ctx* ctx, size_t n_values, const uint16_t* u, const
     HIP_TRY(hipGetLastError());
     return MLKEM_OK;
 }
-int mlkem_sample_ntt_dev(mlkem_ctx* ctx, size_t n, const uint8_t* seeds34, uint16_t* a, void* stream) {
+int mlkem_sample_ntt_retries_dev(mlkem_ctx* ctx, size_t n, const uint8_t* seeds34, uint16_t* a, uint8_t* retries, void* stream) {
     if (!ctx_ok(ctx) || (n && (!seeds34 || !a)) || !aligned16(a)) return MLKEM_ERR_ARG;
-    if (n) sample_ntt_launch(static_cast<hipStream_t>(stream), n, seeds34, a, ctx->ws.wide_max);
+    if (n) sample_ntt_launch(static_cast<hipStream_t>(stream), n, seeds34, a, ctx->ws.wide_max, retries);
     HIP_TRY(hipGetLastError());
     return MLKEM_OK;
+}
+int mlkem_sample_ntt_dev(mlkem_ctx* ctx, size_t n, const uint8_t* seeds34, uint16_t* a, void* stream) {
+    return mlkem_sample_ntt_retries_dev(ctx, n, seeds34, a, nullptr, stream);
 }
 int mlkem_sample_cbd_dev(mlkem_ctx* ctx, int eta, size_t n, const uint8_t* bytes, uint16_t* f, void* stream) {
     if (!ctx_ok(ctx) || (n && (!bytes || !f)) || !aligned16(bytes) || !aligned16(f)) return MLKEM_ERR_ARG;
@@ -998,17 +1001,19 @@ static int host_ntt(bool inverse, size_t n, const uint16_t* in, uint16_t* out) {
 int mlkem_ntt(size_t n, const uint16_t* f, uint16_t* fh) { return host_ntt(false, n, f, fh); }
 int mlkem_intt(size_t n, const uint16_t* fh, uint16_t* f) { return host_ntt(true, n, fh, f); }
 
-int mlkem_sample_ntt(size_t n, const uint8_t* seeds34, uint16_t* a_hat) {
+int mlkem_sample_ntt_retries(size_t n, const uint8_t* seeds34, uint16_t* a_hat, uint8_t* retries) {
     if (n && (!seeds34 || !a_hat)) return MLKEM_ERR_ARG;
     MLKEM_HOST_PROLOGUE()
     if (n == 0) return MLKEM_OK;
-    DevBuf bi, bo;
-    if ((rc = bi.alloc(n * 34)) || (rc = bo.alloc(n * 512))) return rc;
+    DevBuf bi, bo, br;
+    if ((rc = bi.alloc(n * 34)) || (rc = bo.alloc(n * 512)) || (retries && (rc = br.alloc(n)))) return rc;
     HIP_TRY(hipMemcpy(bi.p, seeds34, n * 34, hipMemcpyHostToDevice));
-    if ((rc = mlkem_sample_ntt_dev(ctx, n, bi.as<uint8_t>(), bo.as<uint16_t>(), nullptr))) return rc;
+    if ((rc = mlkem_sample_ntt_retries_dev(ctx, n, bi.as<uint8_t>(), bo.as<uint16_t>(), retries ? br.as<uint8_t>() : nullptr, nullptr))) return rc;
     HIP_TRY(hipMemcpy(a_hat, bo.p, n * 512, hipMemcpyDeviceToHost));
+    if (retries) HIP_TRY(hipMemcpy(retries, br.p, n, hipMemcpyDeviceToHost));
     return MLKEM_OK;
 }
+int mlkem_sample_ntt(size_t n, const uint8_t* seeds34, uint16_t* a_hat) { return mlkem_sample_ntt_retries(n, seeds34, a_hat, nullptr); }
 int mlkem_sample_cbd(int eta, size_t n, const uint8_t* bytes, uint16_t* f) {
     if ((eta != 2 && eta != 3) || (n && (!bytes || !f))) return MLKEM_ERR_ARG;
     MLKEM_HOST_PROLOGUE()

@@ -609,6 +609,7 @@ struct SampleArgs {
     uint32_t resume_cap;
     int list_mode;            // k_sample only: take the sponge indices from `leftover` (grid-stride)
     int prf_rate;             // 0 / 168: PRF on SHAKE128 like the reference (F2) ; 136: SHAKE256 (FIPS 203 mode)
+    uint8_t* retries;         // XOF role, direct mode (may be null): per sponge, how often the seed was mutated (ml_kem.c:237-242)
 };
 
 // PRF with eta = 3 squeezes 192 bytes: dwords 32 .. RATE/4-1 of the first block are still unwritten, then one more
@@ -725,6 +726,7 @@ __global__ void __launch_bounds__(WAVE) k_sample(SampleArgs a) {
             i1 = sp[33];
         }
         int16_t* myring = ring + l * RING_STRIDE;
+        unsigned nretry = 0;
         int cnt = 0, flushed = 0;
         bool fresh = true;      // (re)initialise the sponge: first pass, or the reference's seed-mutation retry
         int blk = 0;            // squeeze blocks consumed since the last (re)initialisation
@@ -757,9 +759,11 @@ __global__ void __launch_bounds__(WAVE) k_sample(SampleArgs a) {
                 i0 = (i0 + 1) & 0xFFu;
                 i1 = (i1 + 1) & 0xFFu;
                 fresh = true;
+                nretry++;
             }
             if (__ballot(cnt < 256) == 0) break;
         }
+        if (a.retries && valid && !a.list_mode) a.retries[g] = (uint8_t)(nretry < 255u ? nretry : 255u);
         wave_lds_fence();
       }
     } else {

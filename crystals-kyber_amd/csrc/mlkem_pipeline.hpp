@@ -574,13 +574,13 @@ inline int compress_values_launch(stream_t st, bool decompress, int d, size_t n,
 // stand-alone SampleNTT over explicit 34-byte seeds: the general kernel in direct mode
 // (calls of at most `wave_max` seeds: one sponge per wave, mlkem_small.hpp -- the ml_kem.h shim's SampleNTT is a call of one)
 template <int QB = KQ, int CAP = SAMPLE_CAP>
-inline void sample_ntt_launch(stream_t st, size_t n, const uint8_t* seeds34, uint16_t* out, size_t wave_max = 0) {
+inline void sample_ntt_launch(stream_t st, size_t n, const uint8_t* seeds34, uint16_t* out, size_t wave_max = 0, uint8_t* retries = nullptr) {
     if (n <= wave_max) {
-        launch("k_sample_xof", k_sample_ntt_w<QB, CAP>, n, WAVE, st, n, seeds34, out);
+        launch("k_sample_xof", k_sample_ntt_w<QB, CAP>, n, WAVE, st, n, seeds34, out, retries);
         return;
     }
     SampleArgs a{};
-    a.n_xof = n; a.rho = seeds34; a.rho_stride = 34; a.K = 0; a.A = out;
+    a.n_xof = n; a.rho = seeds34; a.rho_stride = 34; a.K = 0; a.A = out; a.retries = retries;
     a.xof_blocks = (unsigned)ceil_div(n, WAVE);
     launch("k_sample_xof", k_sample<QB, CAP>, (size_t)a.xof_blocks, WAVE, st, a);
 }

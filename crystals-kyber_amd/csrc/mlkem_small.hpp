@@ -46,7 +46,8 @@ constexpr int XOF_LDS_WORDS = 44;   // 168 squeezed bytes + the dword the last t
 // ------------------------------------------------------------------------------------------------
 // `seed`: bytes [8 i, 8 i + 8) of rho in the SIMD lanes of Keccak index i < 4 (copies included), anything elsewhere
 template <int QB = KQ, int CAP = SAMPLE_CAP>
-__device__ __forceinline__ void wk_sample_ntt_seed(const WkLane& c, uint2 seed, unsigned i0, unsigned i1, uint16_t* poly, uint32_t* sq) {
+// Returns the number of seed mutations (retries) it took: 0 for every real SHAKE stream.
+__device__ __forceinline__ unsigned wk_sample_ntt_seed(const WkLane& c, uint2 seed, unsigned i0, unsigned i1, uint16_t* poly, uint32_t* sq) {
     static_assert(CAP > 224 && CAP <= 280, "the limit falls into the fifth squeeze block");
     const int i = wk_index();
     const bool prim = wk_primary();
@@ -54,6 +55,7 @@ __device__ __forceinline__ void wk_sample_ntt_seed(const WkLane& c, uint2 seed, 
     if (!(i >= 0 && i < 4)) { seed.x = 0; seed.y = 0; }
     const unsigned bo = 3u * l, w = bo >> 2, sh = 8u * (bo & 3u);   // triple l of a block: bytes 3 l .. 3 l + 2
     const unsigned long long below = (1ull << l) - 1ull;
+    unsigned retries = 0;
     for (;;) {
         WkState a;
         a.lo = seed.x; a.hi = seed.y;
@@ -82,7 +84,9 @@ __device__ __forceinline__ void wk_sample_ntt_seed(const WkLane& c, uint2 seed, 
         if (cnt >= 256u) break;
         i0 = (i0 + 1u) & 0xFFu;    // ml_kem.c:237-242: B[32]++, B[33]++ and start over
         i1 = (i1 + 1u) & 0xFFu;
+        retries++;
     }
+    return retries;
 }
 
 // rho: 32 bytes, 8-byte aligned
@@ -95,8 +99,9 @@ __device__ __forceinline__ void wk_sample_ntt(const WkLane& c, const uint8_t* rh
     wk_sample_ntt_seed<QB, CAP>(c, seed, i0, i1, poly, sq);
 }
 // k_sample_ntt_w — stand-alone SampleNTT over explicit 34-byte seeds (any alignment), one sponge per wave
+// retries (may be null): per seed, how often the reference would have bumped B[32], B[33] (ml_kem.c:237-242), saturating at 255
 template <int QB = KQ, int CAP = SAMPLE_CAP>
-__global__ void __launch_bounds__(WAVE) k_sample_ntt_w(size_t n, const uint8_t* __restrict__ seeds34, uint16_t* __restrict__ out) {
+__global__ void __launch_bounds__(WAVE) k_sample_ntt_w(size_t n, const uint8_t* __restrict__ seeds34, uint16_t* __restrict__ out, uint8_t* __restrict__ retries) {
     __shared__ uint32_t sq[XOF_LDS_WORDS];
     __shared__ uint2 rc_table[WK_RC_ENTRIES];
     const size_t g = blockIdx.x;
@@ -112,7 +117,8 @@ __global__ void __launch_bounds__(WAVE) k_sample_ntt_w(size_t n, const uint8_t* 
     }
     WkLane c;
     wk_lane_init(c, rc_table);
-    wk_sample_ntt_seed<QB, CAP>(c, seed, sp[32], sp[33], out + g * 256, sq);
+    const unsigned r = wk_sample_ntt_seed<QB, CAP>(c, seed, sp[32], sp[33], out + g * 256, sq);
+    if (retries && lane_id() == 0) retries[g] = (uint8_t)(r < 255u ? r : 255u);
 }
 
 // ------------------------------------------------------------------------------------------------

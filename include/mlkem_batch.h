@@ -166,6 +166,11 @@ MLKEM_API int mlkem_compress_dev(mlkem_ctx* ctx, int d, size_t n, const uint16_t
 MLKEM_API int mlkem_decompress_dev(mlkem_ctx* ctx, int d, size_t n, const uint16_t* y, uint16_t* x, void* stream);
 /* replaces SampleNTT(B)        ml_kem.c:189-245 ; seeds : n x 34 bytes (packed) */
 MLKEM_API int mlkem_sample_ntt_dev(mlkem_ctx* ctx, size_t n, const uint8_t* seeds34, uint16_t* a_hat, void* stream);
+/* The same with retries[i] (n bytes, may be NULL) = how often the reference's SampleNTT would have incremented B[32] and B[33] of
+ * seed i before it succeeded (ml_kem.c:221-242: more than 278 triples consumed; probability < 2^-300 per seed, so always 0 in
+ * practice).  a_hat[i] is the polynomial of the seed with bytes 32, 33 advanced by retries[i]; the shim writes the advanced bytes
+ * back into the caller's buffer like the reference does. */
+MLKEM_API int mlkem_sample_ntt_retries_dev(mlkem_ctx* ctx, size_t n, const uint8_t* seeds34, uint16_t* a_hat, uint8_t* retries, void* stream);
 /* replaces SamplePolyCBD(B, eta) ml_kem.c:253-275 ; bytes : n x 64*eta */
 MLKEM_API int mlkem_sample_cbd_dev(mlkem_ctx* ctx, int eta, size_t n, const uint8_t* bytes, uint16_t* f, void* stream);
 /* replaces PRF(s, b, eta)      ml_kem.c:496-515 (SHAKE128!) ; in : n x 33 bytes (s || b) ; out : n x 64*eta */
@@ -207,6 +212,7 @@ MLKEM_API int mlkem_intt(size_t n, const uint16_t* f_hat, uint16_t* f);
 /* SampleNTT (ml_kem.c:189-245) and SamplePolyCBD (ml_kem.c:253-275) over host buffers: n x 34 seed bytes /
  * n x 64*eta bytes -> n x uint16[256].  They back the reference's externally visible primitives in the drop-in shim. */
 MLKEM_API int mlkem_sample_ntt(size_t n, const uint8_t* seeds34, uint16_t* a_hat);
+MLKEM_API int mlkem_sample_ntt_retries(size_t n, const uint8_t* seeds34, uint16_t* a_hat, uint8_t* retries);
 MLKEM_API int mlkem_sample_cbd(int eta, size_t n, const uint8_t* bytes, uint16_t* f);
 MLKEM_API int mlkem_keccak_sponge(unsigned rate, size_t n, const uint8_t* padded, unsigned nblocks, uint8_t* out, unsigned outlen);
 /* Compress / Decompress (ml_kem.c:83-119) over n host values, any d in 1..12 (reference test Test_Archive/CompressDecompress_test04.c) */

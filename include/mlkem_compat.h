@@ -78,8 +78,8 @@ unsigned char* sha3_s(const char* cstr, unsigned int m, unsigned int d, unsigned
  * NTT_test08.c call them).  `union integer` (ml_kem.c:20-23) is a 4-byte cell like `union byte`: the coefficient is
  * the 12-bit field `t` in bits 0-11; inputs are read through `t` (mod 2^12), outputs are canonical in [0, q).
  *   symbol          replaced definition     in -> out (malloc()ed for the caller)
- *   SampleNTT       ml_kem.c:189-245        B[34] cells -> 256 cells     (the caller's B is NOT touched: the reference
- *                                           bumps B[32], B[33] on its 279-triple retry, probability < 2^-200)
+ *   SampleNTT       ml_kem.c:189-245        B[34] cells -> 256 cells     (like the reference, B[32].e and B[33].e are
+ *                                           incremented once per 279-triple retry, probability < 2^-300: mlkem_sample_ntt_retries)
  *   SamplePolyCBD   ml_kem.c:253-275        B[64 n] cells, n = eta in {2, 3} -> 256 cells
  *   NTT             ml_kem.c:287-329        256 cells -> 256 cells
  *   InverseNTT      ml_kem.c:336-384        256 cells -> 256 cells */

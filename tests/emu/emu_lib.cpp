@@ -170,12 +170,12 @@ int emu_sample_matrix_bounded(int variant, int k, size_t n, const uint8_t* rho, 
     default: return -1;
     }
 }
-int emu_sample_ntt_bounded(int variant, int wave, size_t n, const uint8_t* seeds, uint16_t* out) {
+int emu_sample_ntt_bounded(int variant, int wave, size_t n, const uint8_t* seeds, uint16_t* out, uint8_t* retries) {
     const size_t wm = wave ? n : 0;
     switch (variant) {
-    case 0: sample_ntt_launch<KQ, SAMPLE_CAP>(nullptr, n, seeds, out, wm); return 0;
-    case 1: sample_ntt_launch<1900, 278>(nullptr, n, seeds, out, wm); return 0;
-    case 2: sample_ntt_launch<2100, 250>(nullptr, n, seeds, out, wm); return 0;
+    case 0: sample_ntt_launch<KQ, SAMPLE_CAP>(nullptr, n, seeds, out, wm, retries); return 0;
+    case 1: sample_ntt_launch<1900, 278>(nullptr, n, seeds, out, wm, retries); return 0;
+    case 2: sample_ntt_launch<2100, 250>(nullptr, n, seeds, out, wm, retries); return 0;
     default: return -1;
     }
 }

@@ -600,18 +600,21 @@ def test_emu_sampler_fifth_block_cap_and_seed_mutation_retry(emu, oracle, varian
     ws = [oracle.sample_ntt_bounded(s34[i], bound, limit) for i in range(ns)]
     wpoly = np.stack([w[0] for w in ws])
     assert sum(w[1] >= 1 for w in ws) >= 60
-    out = np.zeros((ns, 256), np.uint16)
-    assert emu.emu_sample_ntt_bounded(variant, 0, C.c_size_t(ns), p8(s34), p16(out)) == 0
+    out, rt = np.zeros((ns, 256), np.uint16), np.full(ns, 77, np.uint8)
+    assert emu.emu_sample_ntt_bounded(variant, 0, C.c_size_t(ns), p8(s34), p16(out), p8(rt)) == 0
     assert (out == wpoly).all()
+    # the retry counts the shim uses to advance the caller's B[32], B[33] like the reference does (ml_kem.c:237-242)
+    assert rt.tolist() == [w[1] for w in ws]
+    assert all(((s34[i, 32] + int(rt[i])) & 0xFF, (s34[i, 33] + int(rt[i])) & 0xFF) == (int(ws[i][2][32]), int(ws[i][2][33])) for i in range(ns))
     # one sponge per wave (64 host threads per sponge, a barrier per cross-lane operation: slow): 4 seeds chosen by their
     # retry count -- none, one (twice), two or more
     r_of = np.array([w[1] for w in ws])
     pick = np.concatenate([np.nonzero(r_of == 0)[0][:1], np.nonzero(r_of == 1)[0][:2], np.nonzero(r_of >= 2)[0][:1]])
     assert len(pick) == 4
     sw = np.ascontiguousarray(s34[pick])
-    out = np.zeros((len(pick), 256), np.uint16)
-    assert emu.emu_sample_ntt_bounded(variant, 1, C.c_size_t(len(pick)), p8(sw), p16(out)) == 0
-    assert (out == wpoly[pick]).all()
+    out, rt = np.zeros((len(pick), 256), np.uint16), np.full(len(pick), 77, np.uint8)
+    assert emu.emu_sample_ntt_bounded(variant, 1, C.c_size_t(len(pick)), p8(sw), p16(out), p8(rt)) == 0
+    assert (out == wpoly[pick]).all() and rt.tolist() == r_of[pick].tolist()
 
 
 def test_emu_sampler_templates_at_product_parameters_and_wave_form(emu, oracle):
@@ -624,6 +627,6 @@ def test_emu_sampler_templates_at_product_parameters_and_wave_form(emu, oracle):
     s34[7] = [2 * i for i in range(34)]                       # Test_Archive/NTT_test08.c
     want = np.stack([oracle.sample_ntt(s34[i]) for i in range(ns)])
     for wave in (0, 1):
-        out = np.zeros((ns, 256), np.uint16)
-        assert emu.emu_sample_ntt_bounded(0, wave, C.c_size_t(ns), p8(s34), p16(out)) == 0
-        assert (out == want).all(), wave
+        out, rt = np.zeros((ns, 256), np.uint16), np.full(ns, 9, np.uint8)
+        assert emu.emu_sample_ntt_bounded(0, wave, C.c_size_t(ns), p8(s34), p16(out), p8(rt)) == 0
+        assert (out == want).all() and not rt.any(), wave

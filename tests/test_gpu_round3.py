@@ -408,3 +408,22 @@ def test_default_path_switches_at_their_boundaries(pkg, torch, oracle, n):
     keep = np.arange(n) != n // 2
     assert (same[keep] == ~tam[keep]).all()
     e.close()
+
+
+def test_sample_ntt_reports_zero_retries_and_the_shim_leaves_real_seeds_alone(pkg, torch, oracle):
+    """mlkem_sample_ntt_retries: the polynomial of every seed equals the oracle's and the retry count is 0 (a real SHAKE128 stream
+    never exhausts 278 triples), for the lane-sliced form (3000 seeds) and the one-sponge-per-wave form (40 seeds); the counts are
+    what the shim adds to the caller's B[32], B[33] as the reference does (ml_kem.c:237-242; the non-zero case runs in the CPU
+    tier with a lowered acceptance bound)."""
+    import ctypes as C
+    lib = pkg.load_library()
+    lib.mlkem_sample_ntt_retries.argtypes = [C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
+    for n in (3000, 40):
+        s34 = np.concatenate([seeds("rt-s", n, 7), seeds("rt-t", n, 8)[:, :2]], axis=1).astype(np.uint8)
+        out, rt = np.zeros((n, 256), np.uint16), np.full(n, 5, np.uint8)
+        assert lib.mlkem_sample_ntt_retries(n, s34.ctypes.data, out.ctypes.data, rt.ctypes.data) == 0
+        assert not rt.any()
+        for i in range(0, n, max(1, n // 200)):
+            assert (out[i] == oracle.sample_ntt(s34[i])).all(), i
+    out2 = np.zeros((40, 256), np.uint16)
+    assert lib.mlkem_sample_ntt_retries(40, s34.ctypes.data, out2.ctypes.data, None) == 0 and (out2 == out).all()
