@@ -470,7 +470,7 @@ int mlkem_hash_dev(mlkem_ctx* ctx, int kind, size_t n, const uint8_t* msg, unsig
 int mlkem_keccak_sponge_dev(mlkem_ctx* ctx, unsigned rate, size_t n, const uint8_t* padded, unsigned nblocks, uint8_t* out,
                             unsigned outlen, size_t out_stride, void* stream) {
     if (!ctx_ok(ctx) || (n && (!padded || !out)) || !aligned16(padded) || !aligned16(out)) return MLKEM_ERR_ARG;
-    if (n && sponge_raw_launch(static_cast<hipStream_t>(stream), rate, n, padded, nblocks, out, outlen, out_stride)) return MLKEM_ERR_ARG;
+    if (n && sponge_raw_launch(static_cast<hipStream_t>(stream), rate, n, padded, nblocks, out, outlen, out_stride, ctx->ws.wide_max)) return MLKEM_ERR_ARG;
     HIP_TRY(hipGetLastError());
     return MLKEM_OK;
 }
@@ -493,7 +493,7 @@ int mlkem_bytes_to_cells_dev(mlkem_ctx* ctx, size_t n, const uint8_t* bytes, uin
 // reference's latent bug for (n + suffix + 2) == 0 mod r.  Returns the number of blocks, or a negative error.
 int mlkem_sha3_pad_suffix(const uint8_t* msg_bits, size_t nbits, const uint8_t* sfx_bits, unsigned nsfx, unsigned rate,
                           uint8_t* padded, size_t padded_cap) {
-    if (rate == 0 || rate > 200 || (rate & 7) || nsfx > 8 || (nsfx && !sfx_bits)) return MLKEM_ERR_ARG;
+    if (rate == 0 || rate >= 200 || nsfx > 8 || (nsfx && !sfx_bits)) return MLKEM_ERR_ARG;   // any byte rate: capacity 8 .. 1592 bits
     const size_t sbits = nsfx, rbits = (size_t)rate * 8;
     const size_t nblocks = (nbits + sbits + 2 + rbits - 1) / rbits;
     if (nblocks * rate > padded_cap || !padded || (nbits && !msg_bits)) return MLKEM_ERR_ARG;

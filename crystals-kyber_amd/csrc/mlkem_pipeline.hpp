@@ -610,9 +610,16 @@ inline void cells_launch(stream_t st, bool to_bytes, size_t n, const void* in, v
 }
 
 // bare sponge over pre-padded messages (sha3.h front-ends); rate in bytes: 72 / 104 / 136 / 144 / 168
+// (calls of at most `wave_max` messages, and every rate that is not one of the five: one sponge per wave, any rate of 1..199 bytes)
 inline int sponge_raw_launch(stream_t st, unsigned rate, size_t n, const uint8_t* msg, unsigned nblocks, uint8_t* out, unsigned outlen,
-                             size_t out_stride) {
-    if (nblocks == 0 || (out_stride & 3) || out_stride < outlen) return -1;
+                             size_t out_stride, size_t wave_max = 0) {
+    if (nblocks == 0 || out_stride < outlen || rate == 0 || rate >= 200) return -1;
+    const bool standard = rate == 72 || rate == 104 || rate == 136 || rate == 144 || rate == 168;
+    if (n <= wave_max || !standard) {
+        launch("k_sponge_raw", k_sponge_raw_w, n, WAVE, st, n, msg, rate, nblocks, out, outlen, out_stride);
+        return 0;
+    }
+    if (out_stride & 3) return -1;
     const size_t grid = ceil_div(n, WAVE);
     switch (rate) {
     case 72: launch("k_sponge_raw", k_sponge_raw<72>, grid, WAVE, st, n, msg, nblocks, out, outlen, out_stride); break;

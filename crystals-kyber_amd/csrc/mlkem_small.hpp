@@ -121,6 +121,46 @@ __global__ void __launch_bounds__(WAVE) k_sample_ntt_w(size_t n, const uint8_t* 
     if (retries && lane_id() == 0) retries[g] = (uint8_t)(r < 255u ? r : 255u);
 }
 
+// k_sponge_raw_w — the bare Keccak sponge (sha3.c:257-317) over n already-padded messages, one sponge per wave, for ANY rate of
+// 1..199 bytes (the reference's Sponge takes any capacity; sha3_b(..., c, ...) with (1600 - c) % 8 == 0 lands here when the rate is
+// not one of the five SHA-3 / SHAKE rates, and every small call does, whatever its rate).  Message i at msg + i * nblocks * rate,
+// output i at out + i * out_stride; bytes are moved one by one (rates and strides need not be aligned to anything).
+__global__ void __launch_bounds__(WAVE) k_sponge_raw_w(size_t n, const uint8_t* __restrict__ msg, unsigned rate, unsigned nblocks,
+                                                       uint8_t* __restrict__ out, unsigned outlen, size_t out_stride) {
+    __shared__ uint2 rc_table[WK_RC_ENTRIES];
+    const size_t g = blockIdx.x;
+    if (g >= n) return;
+    WkLane c;
+    wk_lane_init(c, rc_table);
+    const int i = wk_index();
+    const unsigned base = 8u * (unsigned)(i < 0 ? 0 : i);   // first byte of the rate block this lane's Keccak lane covers
+    const uint8_t* m = msg + g * (size_t)nblocks * rate;
+    WkState a;
+    a.lo = 0; a.hi = 0;
+    for (unsigned blk = 0; blk < nblocks; blk++) {
+        if (i >= 0) {
+#pragma unroll
+            for (unsigned b = 0; b < 8; b++)
+                if (base + b < rate) {
+                    const uint32_t v = m[(size_t)blk * rate + base + b];
+                    if (b < 4) a.lo ^= v << (8 * b);
+                    else a.hi ^= v << (8 * (b - 4));
+                }
+        }
+        wk_permute(a, c);
+    }
+    uint8_t* o = out + g * out_stride;
+    for (unsigned done = 0; done < outlen; done += rate) {
+        if (done) wk_permute(a, c);
+        const unsigned take = outlen - done < rate ? outlen - done : rate;
+        if (wk_primary()) {
+#pragma unroll
+            for (unsigned b = 0; b < 8; b++)
+                if (base + b < take) o[done + base + b] = (uint8_t)((b < 4 ? a.lo >> (8 * b) : a.hi >> (8 * (b - 4))) & 0xFFu);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // PRF (ml_kem.c:496-515): SHAKE(r[32] || ctr) -> 64 eta bytes at `out`; rate 168 = SHAKE128 like the reference (F2), 136 = SHAKE256
 // ------------------------------------------------------------------------------------------------

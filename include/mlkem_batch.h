@@ -179,9 +179,11 @@ MLKEM_API int mlkem_prf_dev(mlkem_ctx* ctx, int eta, size_t n, const uint8_t* in
  * msg + i*stride (stride % 8 == 0, stride >= len).  kind: 0 = H (32 B out), 1 = G (64 B), 2 = J (32 B, SHAKE128) */
 MLKEM_API int mlkem_hash_dev(mlkem_ctx* ctx, int kind, size_t n, const uint8_t* msg, unsigned len, size_t stride, uint8_t* out, void* stream);
 
-/* replaces Sponge[Keccak-f[1600], pad10*1, r] sha3.c:257-317 on n PRE-PADDED messages of `nblocks` rate blocks each
- * (rate in bytes: 72 / 104 / 136 / 144 / 168), `outlen` bytes squeezed per message into rows of `out_stride`
- * (out_stride % 4 == 0).  Used by the sha3.h front-ends of the drop-in shim (sha3_b / sha3_h / sha3_s). */
+/* replaces Sponge[Keccak-f[1600], pad10*1, r] sha3.c:257-317 on n PRE-PADDED messages of `nblocks` rate blocks each,
+ * `outlen` bytes squeezed per message into rows of `out_stride`.  rate in bytes: ANY value 1..199 (the reference's Sponge takes
+ * any capacity; byte-aligned ones are served: sha3_b(..., c, ...) with (1600 - c) % 8 == 0).  The five SHA-3 / SHAKE rates
+ * 72 / 104 / 136 / 144 / 168 have lane-sliced kernels for large n (out_stride % 4 == 0 there); every other rate, and every call
+ * of at most MLKEM_WIDE_HASH_ITEMS messages, runs one sponge per wavefront.  Used by the sha3.h front-ends of the drop-in shim. */
 MLKEM_API int mlkem_keccak_sponge_dev(mlkem_ctx* ctx, unsigned rate, size_t n, const uint8_t* padded, unsigned nblocks, uint8_t* out,
                             unsigned outlen, size_t out_stride, void* stream);
 /* host helper, no device work: message bits (one per byte) + suffix ("01" hash / "1111" XOF: sha3.c:408-436) + pad10*1

@@ -140,6 +140,10 @@ void emu_cells(int to_bytes, size_t n, const void* in, void* out) { cells_launch
 int emu_sponge_raw(unsigned rate, size_t n, const uint8_t* msg, unsigned nblocks, uint8_t* out, unsigned outlen, size_t out_stride) {
     return sponge_raw_launch(nullptr, rate, n, msg, nblocks, out, outlen, out_stride);
 }
+// the one-sponge-per-wave form (any rate of 1..199 bytes)
+int emu_sponge_raw_wave(unsigned rate, size_t n, const uint8_t* msg, unsigned nblocks, uint8_t* out, unsigned outlen, size_t out_stride) {
+    return sponge_raw_launch(nullptr, rate, n, msg, nblocks, out, outlen, out_stride, n);
+}
 // SampleNTT of a k x k matrix through the production path (three-block main kernel + leftover pass);
 // returns the number of sponges that went through the leftover list.
 int emu_sample_matrix(int k, size_t n, const uint8_t* rho, int transpose, uint16_t* A_out) {

@@ -325,6 +325,32 @@ def test_emu_raw_sponge_nist_examples_and_bit_lengths(emu, oracle, golden):
             assert (out[0] == oracle.sponge_bits(rate, xof, bits, outlen)).all(), (rate, xof, nbits)
 
 
+def test_emu_wave_sponge_any_rate(emu, oracle):
+    """k_sponge_raw_w (mlkem_small.hpp): one sponge per wave, ANY rate of 1..199 bytes -- what sha3_b(..., c, ...) of the shim runs
+    for capacities other than the SHA-3 / SHAKE ones, and what every small call runs.  Host padding (mlkem_sha3_pad_suffix, any
+    byte rate) + the kernel against the oracle's bit-granular sponge (itself pinned against the live reference at these rates:
+    tests/test_oracle_vs_reference.py), incl. outputs of several blocks and an unaligned output stride."""
+    lib = ge.load_package().load_library()
+    rng = np.random.default_rng(9)
+    # (64 host threads per sponge and a barrier per cross-lane operation: ~0.2 s per permutation, so few blocks per case)
+    for rate, nbits, sfx in ((1, 0, (0, 1)), (1, 13, (1, 1, 1, 1)), (13, 8 * 13 + 5, (1, 1)), (72, 40, (0, 1)), (137, 8 * 137 - 2, (1, 1, 1, 1)),
+                             (137, 1203, (0, 1)), (199, 8 * 199 + 5, (1, 1))):
+        if True:
+            bits = rng.integers(0, 2, nbits).astype(np.uint8)
+            sb = np.array(sfx, np.uint8)
+            padded = np.zeros((nbits // (8 * rate) + 2) * rate, np.uint8)
+            nb = lib.mlkem_sha3_pad_suffix(bits.ctypes.data, nbits, sb.ctypes.data, sb.size, rate, padded.ctypes.data, padded.size)
+            assert nb > 0, (rate, nbits)
+            outlen, n = max(3, rate + rate // 2 + 1), 2 if rate == 13 else 1
+            stride = outlen + 3
+            msgs = np.tile(padded[: nb * rate], (n, 1))
+            out = np.zeros((n, stride), np.uint8)
+            assert emu.emu_sponge_raw_wave(rate, C.c_size_t(n), p8(msgs), nb, p8(out), outlen, C.c_size_t(stride)) == 0
+            want = oracle.sponge_bits_sfx(rate, sb, bits, outlen)
+            assert (out[:, :outlen] == want).all() and not out[:, outlen:].any(), (rate, nbits)
+    assert lib.mlkem_sha3_pad_suffix(None, 0, None, 0, 200, None, 0) == -101 and lib.mlkem_sha3_pad_suffix(None, 0, None, 0, 0, None, 0) == -101
+
+
 def test_emu_cell_converters(emu):
     """4-byte `union byte` cells <-> packed bytes; garbage in the upper 24 bits is ignored (F1)."""
     rng = np.random.default_rng(4)

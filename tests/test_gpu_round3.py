@@ -427,3 +427,29 @@ def test_sample_ntt_reports_zero_retries_and_the_shim_leaves_real_seeds_alone(pk
             assert (out[i] == oracle.sample_ntt(s34[i])).all(), i
     out2 = np.zeros((40, 256), np.uint16)
     assert lib.mlkem_sample_ntt_retries(40, s34.ctypes.data, out2.ctypes.data, None) == 0 and (out2 == out).all()
+
+
+def test_sha3_b_of_the_shim_at_any_byte_aligned_capacity(pkg, oracle):
+    """sha3_b(bstr, n, d, c, sfx) through libml_kem.so for capacities other than the SHA-3 / SHAKE ones (the reference's Sponge
+    takes any, sha3.c:257-317): rate = (1600 - c) / 8 bytes, 1..199, on the one-sponge-per-wave kernel; against the oracle (pinned
+    against the live reference at these rates in the CPU tier).  A capacity that is not a multiple of 8 bits is refused."""
+    import ctypes as C
+    shim = C.CDLL(pkg.SHIM_PATH)
+    shim.sha3_b.restype = C.c_void_p
+    shim.sha3_b.argtypes = [C.c_void_p, C.c_uint, C.c_uint, C.c_uint, C.c_void_p]
+    libc = C.CDLL(None)
+    libc.free.argtypes = [C.c_void_p]
+    rng = np.random.default_rng(77)
+    for rate in (1, 13, 100, 137, 199, 136):
+        for nbits in (0, 8 * rate - 3, 1203):
+            bits = rng.integers(0, 2, nbits).astype(np.uint32) | 0xABCD0000      # 4-byte cells, junk above bit 0
+            sfx = np.array([1, 1, 1, 1], np.uint32) | 0x55AA0000
+            d = 8 * (2 * rate + 3)
+            p = shim.sha3_b(bits.ctypes.data, nbits, d, 1600 - 8 * rate, sfx.ctypes.data)
+            assert p, (rate, nbits)
+            got = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint32)), (d,)).copy() & 1
+            libc.free(p)
+            want = oracle.sponge_bits_sfx(rate, np.ones(4, np.uint8), (bits & 1).astype(np.uint8), d // 8)
+            assert (np.packbits(got.astype(np.uint8), bitorder="little") == want).all(), (rate, nbits)
+    sfx = np.array([0, 1, 0, 0], np.uint32)
+    assert not shim.sha3_b(None, 0, 256, 1600 - 1001, sfx.ctypes.data)             # 1001-bit rate: not byte-aligned
