@@ -751,7 +751,7 @@ int stream_op(StreamEngine& e, size_t n, size_t chunk, const std::vector<Span>& 
     // commands and an event cost more than the PCIe round trips inside the kernel: profiles/r04_host_latency.txt.)
     // MLKEM_ZERO_COPY=0 keeps the copy commands.
     static const bool zero_copy = [] { const char* z = getenv("MLKEM_ZERO_COPY"); return !(z && atoi(z) == 0); }();
-    if (rc == MLKEM_OK && single && zero_copy && e.ctx && n <= e.ctx->ws.small_max && n <= e.ctx->ws.cap) {
+    if (rc == MLKEM_OK && single && zero_copy && e.ctx && n <= e.ctx->ws.small_max) {
         BufSet& s = e.set[0];
         bool ok = true;
         for (size_t j = 0; j < spans.size() && ok; j++) {

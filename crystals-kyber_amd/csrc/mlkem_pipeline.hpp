@@ -234,10 +234,10 @@ inline void keygen_run(stream_t st, const ParamSet& p, size_t n, const uint8_t* 
                        const Workspace& ws) {
     const bool kem = z != nullptr;
     const size_t dk_len = kem ? (size_t)p.dk_len : (size_t)(384 * K);
-    if (n && n <= ws.small_max && n <= ws.cap) {   // small call: one launch, one workgroup per item
+    if (n && n <= ws.small_max) {   // small call: one launch, one workgroup per item (its intermediates live in LDS: no scratch)
         const int rate = ws.fips ? 136 : 168;
-        if (kem) launch("k_keygen_small", k_keygen_small<K, ETA1, true>, n, WAVE * SMALL_WAVES, st, n, d, z, ek, dk, ws.A, ws.prf, ws.rho, ws.r, rate);
-        else launch("k_keygen_small", k_keygen_small<K, ETA1, false>, n, WAVE * SMALL_WAVES, st, n, d, z, ek, dk, ws.A, ws.prf, ws.rho, ws.r, rate);
+        if (kem) launch("k_keygen_small", k_keygen_small<K, ETA1, true>, n, WAVE * SMALL_WAVES, st, n, d, z, ek, dk, rate);
+        else launch("k_keygen_small", k_keygen_small<K, ETA1, false>, n, WAVE * SMALL_WAVES, st, n, d, z, ek, dk, rate);
         return;
     }
     for (size_t h0 = 0; h0 < n; h0 += ws.hcap) {
@@ -268,9 +268,8 @@ template <int K, int ETA1, int DU, int DV>
 inline void encaps_run(stream_t st, const ParamSet& p, size_t n, const uint8_t* ek, const uint8_t* m, uint8_t* c, uint8_t* Kout,
                        int32_t* mod_status, const Workspace& ws, const uint8_t* r_user = nullptr) {
     if (n == 0) return;
-    if (!r_user && n <= ws.small_max && n <= ws.cap) {   // small call: one launch, one workgroup per item
-        launch("k_encaps_small", k_encaps_small<K, ETA1, DU, DV>, n, WAVE * SMALL_WAVES, st, n, ek, m, c, Kout, mod_status, ws.A, ws.prf, ws.r,
-               ws.fips ? 136 : 168);
+    if (!r_user && n <= ws.small_max) {   // small call: one launch, one workgroup per item
+        launch("k_encaps_small", k_encaps_small<K, ETA1, DU, DV>, n, WAVE * SMALL_WAVES, st, n, ek, m, c, Kout, mod_status, ws.fips ? 136 : 168);
         return;
     }
     SideFork fork(ws, st, r_user ? (size_t)-1 : n);   // one chunk: A-hat^T (needs rho alone) is sampled beside H(ek) and G
@@ -313,10 +312,10 @@ template <int K, int ETA1, int DU, int DV>
 inline void decaps_run(stream_t st, const ParamSet& p, size_t n, const uint8_t* dk, const uint8_t* c, uint8_t* Kout,
                        int32_t* status, bool hash_check, const Workspace& ws) {
     constexpr int CLEN = 32 * (DU * K + DV);
-    if (n && n <= ws.small_max && n <= ws.cap) {   // small call: one launch, one workgroup per item
+    if (n && n <= ws.small_max) {   // small call: one launch, one workgroup per item
         const int rate = ws.fips ? 136 : 168;
         int32_t* sts = hash_check ? status : (int32_t*)nullptr;
-#define MLKEM_DS(HC, JR) launch("k_decaps_small", k_decaps_small<K, ETA1, DU, DV, HC, JR>, (HC) ? 2 * n : n, WAVE * SMALL_WAVES, st, n, dk, c, Kout, sts, ws.A, ws.prf, ws.r, ws.m, ws.Kp, ws.Kbar, rate)
+#define MLKEM_DS(HC, JR) launch("k_decaps_small", k_decaps_small<K, ETA1, DU, DV, HC, JR>, (HC) ? 2 * n : n, WAVE * SMALL_WAVES, st, n, dk, c, Kout, sts, rate)
         if (hash_check && !ws.fips) MLKEM_DS(true, 168);
         else if (!ws.fips) MLKEM_DS(false, 168);
         else if (hash_check) MLKEM_DS(true, 136);

@@ -7,7 +7,7 @@
 // independent sponges SIDE BY SIDE, each on the one-sponge-per-wave Keccak of mlkem_wkeccak.hpp (3.5 us per permutation for a
 // lone wave instead of 8.8 lane-sliced), meet at workgroup barriers, and hand the sampled matrix and the PRF rows to the
 // arithmetic (keygen2_body / decrypt4_body as the batch kernels run them; encrypt1_body, where the two half-waves share the item's
-// k + 1 output rows) through the call's scratch in HBM:
+// k + 1 output rows) through LDS (SmallHand):
 //   k_encaps_small  stage 1: wave 0: h = H(ek), (K, r) = G(m || h)        | waves 1..: A-hat^T = SampleNTT(rho || j || i)
 //                   stage 2: all waves: PRF(r, n), n = 0..2k
 //                   stage 3: wave 0: K-PKE.Encrypt                                            (ml_kem.c:1093-1130, :776-936)
@@ -187,6 +187,16 @@ __device__ __forceinline__ void wk_prf(const WkLane& c, const uint8_t* r32, unsi
     }
 }
 
+// What the waves of an item's workgroup hand to each other: the sampled matrix, the PRF rows and the 32-byte values.  It lives in
+// LDS -- a producer's ds_write, the workgroup barrier, the consumer's ds_read -- instead of the call's scratch in HBM, where every
+// hand-over cost a store acknowledgement before the barrier and an L2 round trip after it (3-4 us per operation).
+template <int K, int ETA1>
+struct __attribute__((aligned(16))) SmallHand {
+    uint16_t A[K * K * 256];
+    uint8_t prf[(2 * K + 1) * (ETA1 == 3 ? 192 : 128)];
+    uint8_t r[32], m[32], Kp[32], Kbar[32], rho[32];
+};
+
 // H(msg) for a message of `len` bytes (multiple of 8) at `msg`: digest in Keccak lanes 0..3 of `a`
 __device__ __forceinline__ void wk_H(WkState& a, const WkLane& c, const uint8_t* msg, unsigned len) {
     wk_absorb<136, 0x06>(a, c, msg, len, msg, len);
@@ -194,13 +204,13 @@ __device__ __forceinline__ void wk_H(WkState& a, const WkLane& c, const uint8_t*
 
 // ------------------------------------------------------------------------------------------------
 // k_encaps_small — ML-KEM.Encaps_internal (ml_kem.c:1093-1130), one workgroup per item
-//   A, prf, r_ws: the call's scratch (K*K*256 uint16, (2K+1)*PS bytes, 32 bytes per item)
 // ------------------------------------------------------------------------------------------------
 template <int K, int ETA1, int DU, int DV>
 __global__ void __launch_bounds__(WAVE * SMALL_WAVES)
 k_encaps_small(size_t n, const uint8_t* __restrict__ ek, const uint8_t* __restrict__ m, uint8_t* __restrict__ c, uint8_t* __restrict__ Kout,
-               int32_t* __restrict__ mod_status, uint16_t* A, uint8_t* prf, uint8_t* r_ws, int prf_rate) {
+               int32_t* __restrict__ mod_status, int prf_rate) {
     __shared__ K2Lds<K + 1> xl;
+    __shared__ SmallHand<K, ETA1> hand;
     __shared__ uint32_t sq[SMALL_WAVES][XOF_LDS_WORDS];
     __shared__ uint2 rc_tables[SMALL_WAVES][WK_RC_ENTRIES];
     constexpr unsigned EK = 384 * K + 32, PS = (ETA1 == 3) ? 192 : 128, CLEN = 32 * (DU * K + DV);
@@ -208,9 +218,8 @@ k_encaps_small(size_t n, const uint8_t* __restrict__ ek, const uint8_t* __restri
     const size_t item = blockIdx.x;
     if (item >= n) return;
     const uint8_t* my_ek = ek + item * EK;
-    uint16_t* my_A = A + item * (size_t)(K * K * 256);
-    uint8_t* my_prf = prf + item * (size_t)((2 * K + 1) * PS);
-    uint8_t* my_r = r_ws + item * 32;
+    uint16_t* my_A = hand.A;
+    uint8_t *my_prf = hand.prf, *my_r = hand.r;
     WkLane cst;
     wk_lane_init(cst, rc_tables[wave_id()]);
     if (wv == 0) {                                   // h = H(ek) ; (K, r) = G(m || h)
@@ -244,8 +253,9 @@ k_encaps_small(size_t n, const uint8_t* __restrict__ ek, const uint8_t* __restri
 template <int K, int ETA1, int DU, int DV, bool HASH_CHECK, int JRATE>
 __global__ void __launch_bounds__(WAVE * SMALL_WAVES)   // (forced to 128 VGPRs -- two workgroups per CU -- k = 3 spills 88 bytes: not done)
 k_decaps_small(size_t n, const uint8_t* __restrict__ dk, const uint8_t* __restrict__ c, uint8_t* __restrict__ Kout, int32_t* __restrict__ status,
-               uint16_t* A, uint8_t* prf, uint8_t* r_ws, uint8_t* m_ws, uint8_t* Kp_ws, uint8_t* Kbar_ws, int prf_rate) {
+               int prf_rate) {
     __shared__ K2Lds<K + 1> xl;
+    __shared__ SmallHand<K, ETA1> hand;
     __shared__ uint32_t sq[SMALL_WAVES][XOF_LDS_WORDS];
     __shared__ uint2 rc_tables[SMALL_WAVES][WK_RC_ENTRIES];
     constexpr unsigned EK = 384 * K + 32, DK = 768 * K + 96, PS = (ETA1 == 3) ? 192 : 128, CLEN = 32 * (DU * K + DV);
@@ -260,9 +270,8 @@ k_decaps_small(size_t n, const uint8_t* __restrict__ dk, const uint8_t* __restri
     if (item >= n || (check_block && wv != 0)) return;
     const uint8_t* my_dk = dk + item * DK;
     const uint8_t* my_c = c + item * CLEN;
-    uint16_t* my_A = A + item * (size_t)(K * K * 256);
-    uint8_t* my_prf = prf + item * (size_t)((2 * K + 1) * PS);
-    uint8_t *my_r = r_ws + item * 32, *my_m = m_ws + item * 32, *my_Kp = Kp_ws + item * 32, *my_Kbar = Kbar_ws + item * 32;
+    uint16_t* my_A = hand.A;
+    uint8_t *my_prf = hand.prf, *my_r = hand.r, *my_m = hand.m, *my_Kp = hand.Kp, *my_Kbar = hand.Kbar;
     WkLane cst;
     wk_lane_init(cst, rc_tables[wave_id()]);
     const int i = wk_index();
@@ -317,9 +326,9 @@ k_decaps_small(size_t n, const uint8_t* __restrict__ dk, const uint8_t* __restri
 // ------------------------------------------------------------------------------------------------
 template <int K, int ETA1, bool KEM_DK>
 __global__ void __launch_bounds__(WAVE * SMALL_WAVES)
-k_keygen_small(size_t n, const uint8_t* __restrict__ d, const uint8_t* __restrict__ z, uint8_t* ek, uint8_t* dk, uint16_t* A, uint8_t* prf,
-               uint8_t* rho_ws, uint8_t* sigma_ws, int prf_rate) {
+k_keygen_small(size_t n, const uint8_t* __restrict__ d, const uint8_t* __restrict__ z, uint8_t* ek, uint8_t* dk, int prf_rate) {
     __shared__ K2Lds<K> xl;
+    __shared__ SmallHand<K, ETA1> hand;          // prf: 2k rows of it ; r: sigma
     __shared__ uint32_t sq[SMALL_WAVES][XOF_LDS_WORDS];
     __shared__ uint2 rc_tables[SMALL_WAVES][WK_RC_ENTRIES];
     constexpr unsigned EK = 384 * K + 32, DK = KEM_DK ? 768 * K + 96 : 384 * K, PS = (ETA1 == 3) ? 192 : 128;
@@ -327,9 +336,8 @@ k_keygen_small(size_t n, const uint8_t* __restrict__ d, const uint8_t* __restric
     const size_t item = blockIdx.x;
     if (item >= n) return;
     uint8_t *my_ek = ek + item * EK, *my_dk = dk + item * DK;
-    uint16_t* my_A = A + item * (size_t)(K * K * 256);
-    uint8_t* my_prf = prf + item * (size_t)(2 * K * PS);
-    uint8_t *my_rho = rho_ws + item * 32, *my_sigma = sigma_ws + item * 32;
+    uint16_t* my_A = hand.A;
+    uint8_t *my_prf = hand.prf, *my_rho = hand.rho, *my_sigma = hand.r;
     WkLane cst;
     wk_lane_init(cst, rc_tables[wave_id()]);
     const int i = wk_index();
