@@ -453,3 +453,50 @@ def test_sha3_b_of_the_shim_at_any_byte_aligned_capacity(pkg, oracle):
             assert (np.packbits(got.astype(np.uint8), bitorder="little") == want).all(), (rate, nbits)
     sfx = np.array([0, 1, 0, 0], np.uint32)
     assert not shim.sha3_b(None, 0, 256, 1600 - 1001, sfx.ctypes.data)             # 1001-bit rate: not byte-aligned
+
+
+@pytest.mark.parametrize("zero_copy", ("1", "0"))
+def test_small_host_pointer_calls_pinned_registered_and_pageable(pkg, torch, oracle, monkeypatch, zero_copy):
+    """Host-pointer calls of <= Workspace::small_max items issue no copy commands (MLKEM_ZERO_COPY, default on): the kernels
+    read and write pinned host memory -- the caller's buffers where they are pinned (torch) or registered (mlkem_host_register)
+    and the operands exceed 16 KB, the engine's pinned staging otherwise.  64 items (ek 75 KB: direct) and 3 items (staged):
+    same bytes as the oracle for every mix of pageable / pinned / registered operands, with the path on and off."""
+    import subprocess
+    code = r'''
+import sys, numpy as np, torch, ctypes as C
+sys.path.insert(0, %r); sys.path.insert(0, %r + "/tests")
+import __graft_entry__ as ge
+from conftest import seeds
+from oracle.loader import Oracle
+pkg = ge.load_package(); lib = pkg.load_library(); orc = Oracle()
+for n in (64, 3):
+    d, z, m = seeds("zc-d", n, 768), seeds("zc-z", n, 768), seeds("zc-m", n, 768)
+    ek, dk = np.zeros((n, 1184), np.uint8), np.zeros((n, 2400), np.uint8)
+    assert lib.mlkem_keygen(768, n, d.ctypes.data, z.ctypes.data, ek.ctypes.data, dk.ctypes.data) == 0
+    ek_o, dk_o = orc.keygen(768, d, z)
+    assert (ek == ek_o).all() and (dk == dk_o).all()
+    c_o, K_o = orc.encaps(768, ek_o, m)
+    ekp, mp = torch.from_numpy(ek).pin_memory(), torch.from_numpy(m).pin_memory()
+    cp = torch.zeros((n, 1088), dtype=torch.uint8).pin_memory()
+    Kreg = np.zeros((n + 8, 32), np.uint8)
+    assert lib.mlkem_host_register(Kreg.ctypes.data, Kreg.nbytes) == 0
+    assert lib.mlkem_encaps(768, n, ekp.data_ptr(), mp.data_ptr(), cp.data_ptr(), Kreg.ctypes.data) == 0          # all pinned / registered
+    staged = lib.mlkem_stream_last_staged()
+    assert (cp.numpy() == c_o).all() and (Kreg[:n] == K_o).all() and not Kreg[n:].any(), n
+    c2, K2 = np.zeros((n, 1088), np.uint8), np.zeros((n, 32), np.uint8)
+    assert lib.mlkem_encaps(768, n, ekp.data_ptr(), m.ctypes.data, c2.ctypes.data, Kreg.ctypes.data) == 0           # mixed
+    assert (c2 == c_o).all() and (Kreg[:n] == K_o).all()
+    cb = c_o.copy(); cb[n - 1, 7] ^= 1
+    dkp = torch.from_numpy(dk).pin_memory()
+    Kd, st = np.zeros((n, 32), np.uint8), np.ones(n, np.int32)
+    assert lib.mlkem_decaps(768, n, dkp.data_ptr(), cb.ctypes.data, Kd.ctypes.data, st.ctypes.data) == 0
+    Kd_o, st_o = orc.decaps(768, dk_o, cb)
+    assert (Kd == Kd_o).all() and (st == st_o).all() and (Kd[n - 1] != K_o[n - 1]).any()
+    assert lib.mlkem_host_unregister(Kreg.ctypes.data) == 0
+    print("n=%%d staged mask of the all-pinned call: %%d" %% (n, staged))
+''' % (ROOT, ROOT)
+    env = dict(os.environ, MLKEM_ZERO_COPY=zero_copy)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("n=")]
+    assert lines[0].endswith(": 0") and lines[1].endswith(": 15"), lines     # 64 items: in place ; 3 items (<= 16 KB per operand): always staged
