@@ -631,7 +631,7 @@ def test_emu_sampler_fifth_block_cap_and_seed_mutation_retry(emu, oracle, varian
     assert (out == wpoly).all()
     # the retry counts the shim uses to advance the caller's B[32], B[33] like the reference does (ml_kem.c:237-242)
     assert rt.tolist() == [w[1] for w in ws]
-    assert all(((s34[i, 32] + int(rt[i])) & 0xFF, (s34[i, 33] + int(rt[i])) & 0xFF) == (int(ws[i][2][32]), int(ws[i][2][33])) for i in range(ns))
+    assert all(((int(s34[i, 32]) + int(rt[i])) & 0xFF, (int(s34[i, 33]) + int(rt[i])) & 0xFF) == (int(ws[i][2][32]), int(ws[i][2][33])) for i in range(ns))
     # one sponge per wave (64 host threads per sponge, a barrier per cross-lane operation: slow): 4 seeds chosen by their
     # retry count -- none, one (twice), two or more
     r_of = np.array([w[1] for w in ws])
