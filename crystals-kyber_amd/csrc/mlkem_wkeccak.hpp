@@ -15,7 +15,7 @@
 //   pi+chi  lane (x', y') fetches the rotated lanes that pi maps to (x', y'), (x' + 1, y'), (x' + 2, y') with six ds_bpermute_b32
 //           -- the round's only LDS trip; copies fetch what their primary fetches, which is what keeps them valid;
 //   iota    the lanes holding (0, 0), from a 200-byte table of the wave in LDS.
-// 24 VALU + 7 DS instructions per round, 2.9 us per permutation of a lone wave.  Round 3's form (one sponge per half-wave, 18
+// 24 VALU + 7 DS instructions per round, 2.6 us per permutation of a lone wave.  Round 3's form (one sponge per half-wave, 18
 // ds_bpermute per round in three dependent groups) ran 4.8; tools/keccak_wave_ubench.hip measures all forms
 // (profiles/r04_keccak_wave_ubench.txt).
 // Message bytes map 1:1: Keccak lane i = x + 5 y owns bytes [8 i, 8 i + 8) of every rate block, so absorbing is one 8-byte
@@ -135,7 +135,9 @@ __device__ __forceinline__ void wk_canon(WkState& a, const WkLane& c) {
 
 __device__ __forceinline__ void wk_permute(WkState& a, const WkLane& c) {
     const uint2* rcp = c.is00 ? c.rc : c.rc + 24;
-#pragma unroll 1
+    // four rounds per loop iteration: the loop's scalar bookkeeping and the taken branch cost a lone wave ~25 cycles per round
+    // (2.84 -> 2.59 us per permutation; unrolled 8 / 24 times: 2.56 / 2.52, not worth the code)
+#pragma unroll 4
     for (int round = 0; round < 24; round++) {
         const uint2 rc = *rcp;                  // issued first: long since there when iota needs it
         rcp += c.is00 ? 1 : 0;
@@ -195,12 +197,18 @@ __device__ __forceinline__ void wk_absorb(WkState& a, const WkLane& c, const uin
 #pragma unroll 1
     for (unsigned blk = 0; blk < nblocks; blk++) {
         a.lo ^= v.x; a.hi ^= v.y;
-        if (blk + 1 == nblocks) {   // pad10*1: suffix byte at message position `total`, 0x80 at the block's last byte
+        // The next block's load is issued HERE and lands during the permutation.  It must come after the XOR above (the old value
+        // dead, so that the load writes the same registers and nothing waits for it before the loop) and must not sit in a branch:
+        // the first build fetched under `if (not the last block)`, the compiler resolved the loop-carried value with a register
+        // copy right after the load, and every block waited for its HBM round trip before permuting (0.35 us per block).  The last
+        // iteration re-reads its own block (harmless).
+        sched_fence();
+        const bool last = blk + 1 == nblocks;
+        v = fetch(last ? blk : blk + 1);
+        if (last) {                 // pad10*1: suffix byte at message position `total`, 0x80 at the block's last byte
             const unsigned pos = total - blk * RATE;           // < RATE, multiple of 8
             if (i == (int)(pos / 8)) a.lo ^= SUFFIX;
             if (i == NQ - 1) a.hi ^= 0x80000000u;
-        } else {
-            v = fetch(blk + 1);
         }
         wk_permute(a, c);
     }
