@@ -176,6 +176,10 @@ int mlkem_ctx_create(mlkem_ctx** out, int device, size_t chunk_items) {
         long long v = atoll(e);
         if (v >= 0) c->ws.small_max = (size_t)v;
     }
+    if (const char* e = getenv("MLKEM_SMALL_LATENCY_ITEMS")) {   // small calls above this size: four waves per item instead of eight
+        long long v = atoll(e);
+        if (v >= 0) c->ws.small_lat_max = (size_t)v;
+    }
     // fork / join events of one-chunk calls (SideFork, mlkem_pipeline.hpp); the side stream itself comes with the first such call
     // (ctx_arm_side).  MLKEM_SIDE_STREAM=0 keeps every call on the caller's stream; failing to create the events does the same.
     const char* se = getenv("MLKEM_SIDE_STREAM");
@@ -749,9 +753,10 @@ int stream_op(StreamEngine& e, size_t n, size_t chunk, const std::vector<Span>& 
     // registered (and 16-byte aligned), the set's pinned staging buffer otherwise -- so that the call is: memcpy in, ONE launch,
     // stream synchronise, memcpy out.  (Per operation and item the kernels read 1.2-3.5 KB and write 0.03-1.1 KB; four copy
     // commands and an event cost more than the PCIe round trips inside the kernel: profiles/r04_host_latency.txt.)
-    // MLKEM_ZERO_COPY=0 keeps the copy commands.
+    // MLKEM_ZERO_COPY=0 keeps the copy commands.  Measured up to 512 items; larger small calls keep the copy commands.
+    constexpr size_t ZERO_COPY_MAX = 512;
     static const bool zero_copy = [] { const char* z = getenv("MLKEM_ZERO_COPY"); return !(z && atoi(z) == 0); }();
-    if (rc == MLKEM_OK && single && zero_copy && e.ctx && n <= e.ctx->ws.small_max) {
+    if (rc == MLKEM_OK && single && zero_copy && e.ctx && n <= e.ctx->ws.small_max && n <= ZERO_COPY_MAX) {
         BufSet& s = e.set[0];
         bool ok = true;
         for (size_t j = 0; j < spans.size() && ok; j++) {

@@ -114,9 +114,12 @@ struct Workspace {
     size_t hcap = 0;   // h-chunk capacity (items) of the 32-byte arrays
     size_t wide_max = 2048;   // calls of at most this many items hash with one sponge per HALF-WAVE (mlkem_wkeccak.hpp: faster
                               // up to 2048 items, slower from 4096, profiles/r03_batch_sweep.txt); env MLKEM_WIDE_HASH_ITEMS
-    size_t small_max = 512;   // calls of at most this many items run as ONE launch, one workgroup per item (mlkem_small.hpp): one
-                              // workgroup fits a CU, two rounds of 256 still beat the batch path (0.166 against 0.181 ms per pair
-                              // at 512 items, 0.242 against 0.193 at 768: profiles/r04_small_sweep.txt); env MLKEM_SMALL_ITEMS (0: never)
+    size_t small_max = 896;   // calls of at most this many items run as ONE launch, one workgroup per item (mlkem_small.hpp); per pair
+                              // at 768 items 0.160 ms against 0.198 on the batch path, at 1024 0.211 against 0.194
+                              // (profiles/r04_small_sweep.txt); env MLKEM_SMALL_ITEMS (0: never)
+    size_t small_lat_max = 320;   // ... of which calls of at most this many items use eight waves per item (shortest chain: 0.070
+                                  // against 0.083 ms per pair at one item, 0.077 against 0.095 at 256), larger ones four (twice the
+                                  // items per CU: 0.115 against 0.117 at 384, 0.160 against 0.183 at 768); env MLKEM_SMALL_LATENCY_ITEMS
     // measurement aid (mlkem_ctx_debug_stages, tools/energy_probe.py): which kernel families the batch path launches; the
     // outputs of a call with stages missing are meaningless.  1 = hash kernels, 2 = sampler, 4 = K-PKE.Encrypt / KeyGen, 8 = Decrypt
     unsigned stages = 15;
@@ -236,8 +239,13 @@ inline void keygen_run(stream_t st, const ParamSet& p, size_t n, const uint8_t* 
     const size_t dk_len = kem ? (size_t)p.dk_len : (size_t)(384 * K);
     if (n && n <= ws.small_max) {   // small call: one launch, one workgroup per item (its intermediates live in LDS: no scratch)
         const int rate = ws.fips ? 136 : 168;
-        if (kem) launch("k_keygen_small", k_keygen_small<K, ETA1, true>, n, WAVE * SMALL_WAVES, st, n, d, z, ek, dk, rate);
-        else launch("k_keygen_small", k_keygen_small<K, ETA1, false>, n, WAVE * SMALL_WAVES, st, n, d, z, ek, dk, rate);
+#define MLKEM_KS(KEM, NW) launch("k_keygen_small", k_keygen_small<K, ETA1, KEM, NW>, n, WAVE * NW, st, n, d, z, ek, dk, rate)
+        const bool lat = n <= ws.small_lat_max;
+        if (kem && lat) MLKEM_KS(true, SMALL_WAVES);
+        else if (kem) MLKEM_KS(true, SMALL_WAVES_DENSE);
+        else if (lat) MLKEM_KS(false, SMALL_WAVES);
+        else MLKEM_KS(false, SMALL_WAVES_DENSE);
+#undef MLKEM_KS
         return;
     }
     for (size_t h0 = 0; h0 < n; h0 += ws.hcap) {
@@ -269,7 +277,11 @@ inline void encaps_run(stream_t st, const ParamSet& p, size_t n, const uint8_t* 
                        int32_t* mod_status, const Workspace& ws, const uint8_t* r_user = nullptr) {
     if (n == 0) return;
     if (!r_user && n <= ws.small_max) {   // small call: one launch, one workgroup per item
-        launch("k_encaps_small", k_encaps_small<K, ETA1, DU, DV>, n, WAVE * SMALL_WAVES, st, n, ek, m, c, Kout, mod_status, ws.fips ? 136 : 168);
+        const int rate = ws.fips ? 136 : 168;
+        if (n <= ws.small_lat_max)
+            launch("k_encaps_small", k_encaps_small<K, ETA1, DU, DV, SMALL_WAVES>, n, WAVE * SMALL_WAVES, st, n, ek, m, c, Kout, mod_status, rate);
+        else
+            launch("k_encaps_small", k_encaps_small<K, ETA1, DU, DV, SMALL_WAVES_DENSE>, n, WAVE * SMALL_WAVES_DENSE, st, n, ek, m, c, Kout, mod_status, rate);
         return;
     }
     SideFork fork(ws, st, r_user ? (size_t)-1 : n);   // one chunk: A-hat^T (needs rho alone) is sampled beside H(ek) and G
@@ -315,11 +327,13 @@ inline void decaps_run(stream_t st, const ParamSet& p, size_t n, const uint8_t* 
     if (n && n <= ws.small_max) {   // small call: one launch, one workgroup per item
         const int rate = ws.fips ? 136 : 168;
         int32_t* sts = hash_check ? status : (int32_t*)nullptr;
-#define MLKEM_DS(HC, JR) launch("k_decaps_small", k_decaps_small<K, ETA1, DU, DV, HC, JR>, (HC) ? 2 * n : n, WAVE * SMALL_WAVES, st, n, dk, c, Kout, sts, rate)
-        if (hash_check && !ws.fips) MLKEM_DS(true, 168);
-        else if (!ws.fips) MLKEM_DS(false, 168);
-        else if (hash_check) MLKEM_DS(true, 136);
-        else MLKEM_DS(false, 136);
+#define MLKEM_DS(HC, JR, NW) launch("k_decaps_small", k_decaps_small<K, ETA1, DU, DV, HC, JR, NW>, (HC) ? 2 * n : n, WAVE * NW, st, n, dk, c, Kout, sts, rate)
+#define MLKEM_DS2(HC, JR) do { if (n <= ws.small_lat_max) MLKEM_DS(HC, JR, SMALL_WAVES); else MLKEM_DS(HC, JR, SMALL_WAVES_DENSE); } while (0)
+        if (hash_check && !ws.fips) MLKEM_DS2(true, 168);
+        else if (!ws.fips) MLKEM_DS2(false, 168);
+        else if (hash_check) MLKEM_DS2(true, 136);
+        else MLKEM_DS2(false, 136);
+#undef MLKEM_DS2
 #undef MLKEM_DS
         return;
     }

@@ -28,7 +28,18 @@
 
 namespace mlkem {
 
-constexpr int SMALL_WAVES = 8;   // 512 threads: two waves per SIMD, i.e. the 256 VGPRs the K-PKE bodies may need (k = 4)
+// Waves per workgroup (template parameter NW of the three kernels).  8 is the latency form: a lone item's nine SampleNTT sponges
+// run on seven waves while wave 0 walks H(ek).  4 is the dense form for calls that fill the chip: half the registers per item,
+// so twice the items per CU, and the item's sponges are dealt out by a counter in LDS (take_job) so that the waves of the serial
+// roles join the sampling when they are through -- four waves then finish about when wave 0's chain does.
+constexpr int SMALL_WAVES = 8, SMALL_WAVES_DENSE = 4;
+
+// The next job number of the workgroup's counter (0, 1, 2, ... in the order the waves ask), the same value in all lanes.
+__device__ __forceinline__ unsigned take_job(uint32_t* counter) {
+    unsigned j = 0;
+    if (lane_id() == 0) j = atomicAdd(counter, 1u);
+    return (unsigned)__shfl((int)j, 0);
+}
 
 #ifdef MLKEM_EMU
 __device__ __forceinline__ void block_barrier() { emu::block_barrier(); }
@@ -205,14 +216,15 @@ __device__ __forceinline__ void wk_H(WkState& a, const WkLane& c, const uint8_t*
 // ------------------------------------------------------------------------------------------------
 // k_encaps_small — ML-KEM.Encaps_internal (ml_kem.c:1093-1130), one workgroup per item
 // ------------------------------------------------------------------------------------------------
-template <int K, int ETA1, int DU, int DV>
-__global__ void __launch_bounds__(WAVE * SMALL_WAVES)
+template <int K, int ETA1, int DU, int DV, int NW>
+__global__ void __launch_bounds__(WAVE * NW)
 k_encaps_small(size_t n, const uint8_t* __restrict__ ek, const uint8_t* __restrict__ m, uint8_t* __restrict__ c, uint8_t* __restrict__ Kout,
                int32_t* __restrict__ mod_status, int prf_rate) {
     __shared__ K2Lds<K + 1> xl;
     __shared__ SmallHand<K, ETA1> hand;
-    __shared__ uint32_t sq[SMALL_WAVES][XOF_LDS_WORDS];
-    __shared__ uint2 rc_tables[SMALL_WAVES][WK_RC_ENTRIES];
+    __shared__ uint32_t sq[NW][XOF_LDS_WORDS];
+    __shared__ uint2 rc_tables[NW][WK_RC_ENTRIES];
+    __shared__ uint32_t next_job;
     constexpr unsigned EK = 384 * K + 32, PS = (ETA1 == 3) ? 192 : 128, CLEN = 32 * (DU * K + DV);
     const int wv = wave_id();
     const size_t item = blockIdx.x;
@@ -222,6 +234,8 @@ k_encaps_small(size_t n, const uint8_t* __restrict__ ek, const uint8_t* __restri
     uint8_t *my_prf = hand.prf, *my_r = hand.r;
     WkLane cst;
     wk_lane_init(cst, rc_tables[wave_id()]);
+    if (threadIdx.x == 0) next_job = 0;
+    block_barrier();
     if (wv == 0) {                                   // h = H(ek) ; (K, r) = G(m || h)
         const int i = wk_index();
         WkState a;
@@ -234,12 +248,12 @@ k_encaps_small(size_t n, const uint8_t* __restrict__ ek, const uint8_t* __restri
         o.x = a.lo; o.y = a.hi;
         if (wk_primary() && i < 4) reinterpret_cast<uint2*>(Kout + item * 32)[i] = o;
         else if (wk_primary() && i < 8) reinterpret_cast<uint2*>(my_r)[i - 4] = o;
-    } else {                                         // A-hat^T[a][b] = SampleNTT(rho || a || b)   (ml_kem.c:817-823)
-        for (int s = wv - 1; s < K * K; s += SMALL_WAVES - 1)
-            wk_sample_ntt(cst, my_ek + 384 * K, (unsigned)(s / K), (unsigned)(s % K), my_A + s * 256, sq[wv]);
     }
+    // A-hat^T[a][b] = SampleNTT(rho || a || b)   (ml_kem.c:817-823): whichever wave is free takes the next entry
+    for (unsigned s; (s = take_job(&next_job)) < (unsigned)(K * K);)
+        wk_sample_ntt(cst, my_ek + 384 * K, s / K, s % K, my_A + s * 256, sq[wv]);
     block_barrier();
-    for (int j = wv; j < 2 * K + 1; j += SMALL_WAVES)
+    for (int j = wv; j < 2 * K + 1; j += NW)
         wk_prf(cst, my_r, (unsigned)j, j < K ? (unsigned)ETA1 : 2u, (unsigned)prf_rate, my_prf + j * PS);
     block_barrier();
     if (wv == 0)
@@ -250,16 +264,16 @@ k_encaps_small(size_t n, const uint8_t* __restrict__ ek, const uint8_t* __restri
 // ------------------------------------------------------------------------------------------------
 // k_decaps_small — KEM_Decaps / Decaps_internal (ml_kem.c:1310-1359, :1136-1225), one workgroup per item
 // ------------------------------------------------------------------------------------------------
-template <int K, int ETA1, int DU, int DV, bool HASH_CHECK, int JRATE>
-__global__ void __launch_bounds__(WAVE * SMALL_WAVES)   // (forced to 128 VGPRs -- two workgroups per CU -- k = 3 spills 88 bytes: not done)
+template <int K, int ETA1, int DU, int DV, bool HASH_CHECK, int JRATE, int NW>
+__global__ void __launch_bounds__(WAVE * NW)   // (forced to 128 VGPRs -- two eight-wave workgroups per CU -- k = 3 spills 88 bytes: not done)
 k_decaps_small(size_t n, const uint8_t* __restrict__ dk, const uint8_t* __restrict__ c, uint8_t* __restrict__ Kout, int32_t* __restrict__ status,
                int prf_rate) {
     __shared__ K2Lds<K + 1> xl;
     __shared__ SmallHand<K, ETA1> hand;
-    __shared__ uint32_t sq[SMALL_WAVES][XOF_LDS_WORDS];
-    __shared__ uint2 rc_tables[SMALL_WAVES][WK_RC_ENTRIES];
+    __shared__ uint32_t sq[NW][XOF_LDS_WORDS];
+    __shared__ uint2 rc_tables[NW][WK_RC_ENTRIES];
+    __shared__ uint32_t next_job;
     constexpr unsigned EK = 384 * K + 32, DK = 768 * K + 96, PS = (ETA1 == 3) ? 192 : 128, CLEN = 32 * (DU * K + DV);
-    constexpr int FIRST_XOF = 2;                     // waves 0, 1 run the serial roles
     const int wv = wave_id();
     // KEM_Decaps' check of the stored H(ek) (9 permutations at k = 3: the longest chain of the operation, and nothing but the
     // status depends on it) runs in workgroups of its own, one live wave each.  They are blocks [0, n): dispatched first, they
@@ -287,6 +301,8 @@ k_decaps_small(size_t n, const uint8_t* __restrict__ dk, const uint8_t* __restri
         if (lane_id() == 0 && status) status[item] = bad ? -5 : 0;
         return;
     }
+    if (threadIdx.x == 0) next_job = 0;
+    block_barrier();
     if (wv == 0) {                                   // m' = K-PKE.Decrypt(dk_pke, c) ; (K', r') = G(m' || h)
         decrypt4_body<K, DU, DV>(0, 1, my_dk, (size_t)DK, my_c, my_m);
         wave_global_fence();
@@ -309,12 +325,12 @@ k_decaps_small(size_t n, const uint8_t* __restrict__ dk, const uint8_t* __restri
         uint2 o;
         o.x = a.lo; o.y = a.hi;
         if (prim && i < 4) reinterpret_cast<uint2*>(my_Kbar)[i] = o;
-    } else {                                         // A-hat^T of the re-encryption (rho sits in dk.ek)
-        for (int s = wv - FIRST_XOF; s < K * K; s += SMALL_WAVES - FIRST_XOF)
-            wk_sample_ntt(cst, my_dk + 768 * K, (unsigned)(s / K), (unsigned)(s % K), my_A + s * 256, sq[wv]);
     }
+    // A-hat^T of the re-encryption (rho sits in dk.ek): whichever wave is free takes the next entry
+    for (unsigned s; (s = take_job(&next_job)) < (unsigned)(K * K);)
+        wk_sample_ntt(cst, my_dk + 768 * K, s / K, s % K, my_A + s * 256, sq[wv]);
     block_barrier();
-    for (int j = wv; j < 2 * K + 1; j += SMALL_WAVES)
+    for (int j = wv; j < 2 * K + 1; j += NW)
         wk_prf(cst, my_r, (unsigned)j, j < K ? (unsigned)ETA1 : 2u, (unsigned)prf_rate, my_prf + j * PS);
     block_barrier();
     if (wv == 0)
@@ -324,13 +340,14 @@ k_decaps_small(size_t n, const uint8_t* __restrict__ dk, const uint8_t* __restri
 // ------------------------------------------------------------------------------------------------
 // k_keygen_small — ML-KEM.KeyGen_internal (ml_kem.c:1034-1084) ; KEM_DK = false: K-PKE.KeyGen alone (dk = the 384k bytes of s-hat)
 // ------------------------------------------------------------------------------------------------
-template <int K, int ETA1, bool KEM_DK>
-__global__ void __launch_bounds__(WAVE * SMALL_WAVES)
+template <int K, int ETA1, bool KEM_DK, int NW>
+__global__ void __launch_bounds__(WAVE * NW)
 k_keygen_small(size_t n, const uint8_t* __restrict__ d, const uint8_t* __restrict__ z, uint8_t* ek, uint8_t* dk, int prf_rate) {
     __shared__ K2Lds<K> xl;
     __shared__ SmallHand<K, ETA1> hand;          // prf: 2k rows of it ; r: sigma
-    __shared__ uint32_t sq[SMALL_WAVES][XOF_LDS_WORDS];
-    __shared__ uint2 rc_tables[SMALL_WAVES][WK_RC_ENTRIES];
+    __shared__ uint32_t sq[NW][XOF_LDS_WORDS];
+    __shared__ uint2 rc_tables[NW][WK_RC_ENTRIES];
+    __shared__ uint32_t next_job;
     constexpr unsigned EK = 384 * K + 32, DK = KEM_DK ? 768 * K + 96 : 384 * K, PS = (ETA1 == 3) ? 192 : 128;
     const int wv = wave_id();
     const size_t item = blockIdx.x;
@@ -357,11 +374,13 @@ k_keygen_small(size_t n, const uint8_t* __restrict__ d, const uint8_t* __restric
         if (prim && i < 4) reinterpret_cast<uint2*>(my_rho)[i] = o;
         else if (prim && i < 8) reinterpret_cast<uint2*>(my_sigma)[i - 4] = o;
     }
+    if (threadIdx.x == 0) next_job = 0;
     block_barrier();
-    // A-hat[a][b] = SampleNTT(rho || b || a) (ml_kem.c:686-693) and the 2k PRF rows (s: n = 0..k-1, e: n = k..2k-1, all eta1)
-    for (int j = wv; j < K * K + 2 * K; j += SMALL_WAVES) {
-        if (j < K * K) wk_sample_ntt(cst, my_rho, (unsigned)(j % K), (unsigned)(j / K), my_A + j * 256, sq[wv]);
-        else wk_prf(cst, my_sigma, (unsigned)(j - K * K), (unsigned)ETA1, (unsigned)prf_rate, my_prf + (j - K * K) * PS);
+    // A-hat[a][b] = SampleNTT(rho || b || a) (ml_kem.c:686-693) and the 2k PRF rows (s: n = 0..k-1, e: n = k..2k-1, all eta1),
+    // dealt out longest first
+    for (unsigned j; (j = take_job(&next_job)) < (unsigned)(K * K + 2 * K);) {
+        if (j < (unsigned)(K * K)) wk_sample_ntt(cst, my_rho, j % K, j / K, my_A + j * 256, sq[wv]);
+        else wk_prf(cst, my_sigma, j - K * K, (unsigned)ETA1, (unsigned)prf_rate, my_prf + (j - K * K) * PS);
     }
     block_barrier();
     if (wv == 0) {

@@ -537,16 +537,17 @@ def test_emu_one_sponge_per_wave_hash_kernels(emu, oracle, pset, fips):
         oracle.set_conformance(False)
 
 
-@pytest.mark.parametrize("pset,fips", ((512, 0), (768, 0), (1024, 1)))
-def test_emu_one_workgroup_per_item_kernels(emu, oracle, pset, fips):
+@pytest.mark.parametrize("pset,fips,waves", ((512, 0, 4), (768, 0, 8), (1024, 1, 4)))
+def test_emu_one_workgroup_per_item_kernels(emu, oracle, pset, fips, waves):
     """mlkem_small.hpp (calls of at most `small_max` items): KeyGen, Encaps and Decaps each as ONE launch, a workgroup of eight
-    waves per item -- wave-level SampleNTT (ballot + prefix-count compaction), PRF, H / G / J and the K-PKE bodies behind
-    workgroup barriers.  An untouched and a tampered ciphertext (two items for 768, one for the others), then a corrupted stored
+    (latency form) or four (dense form) waves per item -- wave-level SampleNTT (ballot + prefix-count compaction) dealt out by a
+    counter in LDS, PRF, H / G / J and the K-PKE bodies behind workgroup barriers.  An untouched and a tampered ciphertext (two items for 768, one for the others), then a corrupted stored
     H(ek) with the untouched ciphertext; bit for bit against the oracle (reference mode for 512 / 768, FIPS 203 mode -- PRF and J on SHAKE256 -- for 1024)."""
     n = 2 if pset == 768 else 1                        # 512 host threads per item: the second item only where its index matters once
     ekl, dkl, cl = SIZES[pset]
     emu.emu_conformance(fips)
     emu.emu_small(C.c_size_t(16))
+    emu.emu_small_latency(C.c_size_t(16 if waves == 8 else 0))
     try:
         d, z, m = seeds("sm-d", n, pset), seeds("sm-z", n, pset), seeds("sm-m", n, pset)
         oracle.set_conformance(bool(fips))
@@ -573,6 +574,7 @@ def test_emu_one_workgroup_per_item_kernels(emu, oracle, pset, fips):
         assert st[0] == -5 and (Kd[0] == oracle.decaps_internal(pset, dkb[0], c[0])).all()   # G ran on the corrupted stored h
     finally:
         emu.emu_small(C.c_size_t(0))
+        emu.emu_small_latency(C.c_size_t(128))
         emu.emu_conformance(0)
         oracle.set_conformance(False)
 

@@ -344,8 +344,10 @@ def test_every_ciphertext_byte_takes_part_in_the_compare(pkg, torch, oracle, pse
 # ---- calls of one chunk: matrix sampling on the context's side stream ------------------------------------------------------
 @pytest.mark.parametrize("env", ({}, {"MLKEM_SMALL_ITEMS": "0"}, {"MLKEM_SMALL_ITEMS": "0", "MLKEM_SIDE_STREAM": "0"},
                                  {"MLKEM_SMALL_ITEMS": "0", "MLKEM_WIDE_HASH_ITEMS": "0"}, {"MLKEM_SMALL_ITEMS": "0", "MLKEM_WIDE_HASH_ITEMS": "100000"},
-                                 {"MLKEM_SMALL_ITEMS": "100000"}),
-                         ids=("default", "side-stream", "one-stream", "lane-sliced-hashes", "one-sponge-per-wave-hashes", "one-workgroup-per-item"))
+                                 {"MLKEM_SMALL_ITEMS": "100000", "MLKEM_SMALL_LATENCY_ITEMS": "100000"},
+                                 {"MLKEM_SMALL_ITEMS": "100000", "MLKEM_SMALL_LATENCY_ITEMS": "0"}),
+                         ids=("default", "side-stream", "one-stream", "lane-sliced-hashes", "one-sponge-per-wave-hashes", "one-workgroup-per-item-8-waves",
+                              "one-workgroup-per-item-4-waves"))
 @pytest.mark.parametrize("pset,n", ((768, 1000), (512, 3), (1024, 130)))
 def test_single_chunk_calls_keep_their_results_with_and_without_the_side_stream(pkg, torch, oracle, env, monkeypatch, pset, n):
     """A call that fits one chunk samples A-hat on the context's side stream while H(ek) / G (encaps) or Decrypt and the
@@ -353,7 +355,7 @@ def test_single_chunk_calls_keep_their_results_with_and_without_the_side_stream(
     decaps with different data are queued back to back WITHOUT a synchronisation in between: a matrix sampled too early
     (before the previous call's arithmetic has read the scratch) or joined too late would change bytes.  Same bytes with the
     side stream disabled, with either family of hash kernels forced for every size, and with the one-workgroup-per-item
-    kernels forced on and off (defaults: calls of at most Workspace::small_max items run as one launch per operation,
+    kernels forced on (in their eight-wave and their four-wave form) and off (defaults: calls of at most Workspace::small_max items run as one launch per operation,
     mlkem_small.hpp; up to Workspace::wide_max items the hash kernels carry one sponge per wavefront, mlkem_wkeccak.hpp; larger
     calls hash with one sponge per lane)."""
     for k, v in env.items():
@@ -378,9 +380,10 @@ def test_single_chunk_calls_keep_their_results_with_and_without_the_side_stream(
     e.close()
 
 
-@pytest.mark.parametrize("n", (1, 2, 256, 257, 511, 512, 513, 2047, 2048, 2049))
+@pytest.mark.parametrize("n", (1, 2, 256, 257, 320, 321, 512, 895, 896, 897, 2047, 2048, 2049))
 def test_default_path_switches_at_their_boundaries(pkg, torch, oracle, n):
-    """The sizes either side of Workspace::small_max (512: one workgroup per item, two rounds of 256 | batch kernels; 256 | 257: the end of the first round) and Workspace::wide_max
+    """The sizes either side of Workspace::small_lat_max (320: one workgroup of eight | of four waves per item; 256 | 257: the end
+    of the eight-wave form's first round), Workspace::small_max (896: one workgroup per item | batch kernels) and Workspace::wide_max
     (2048: one sponge per wave + direct sampler | lane-sliced hashes + three-block sampler), default environment, one chunk
     (chunk_items 4096): ML-KEM-768 keygen -> encaps -> decaps with tampered ciphertexts and one corrupted stored hash."""
     pset = 768
@@ -469,7 +472,7 @@ import __graft_entry__ as ge
 from conftest import seeds
 from oracle.loader import Oracle
 pkg = ge.load_package(); lib = pkg.load_library(); orc = Oracle()
-for n in (64, 3):
+for n in (64, 3, 700):      # 700: small kernels, but above the zero-copy size: copy commands
     d, z, m = seeds("zc-d", n, 768), seeds("zc-z", n, 768), seeds("zc-m", n, 768)
     ek, dk = np.zeros((n, 1184), np.uint8), np.zeros((n, 2400), np.uint8)
     assert lib.mlkem_keygen(768, n, d.ctypes.data, z.ctypes.data, ek.ctypes.data, dk.ctypes.data) == 0

@@ -14,20 +14,23 @@ __device__ __forceinline__ void stamp(unsigned long long* s, int k) {
     if (lane_id() == 0) { s[2 * k] = __builtin_amdgcn_s_memtime(); s[2 * k + 1] = __builtin_amdgcn_s_memrealtime(); }
 }
 
-template <int K, int ETA1, int DU, int DV>
-__global__ void __launch_bounds__(WAVE * SMALL_WAVES)
+template <int K, int ETA1, int DU, int DV, int NW>
+__global__ void __launch_bounds__(WAVE * NW)
 k_encaps_stamped(const uint8_t* __restrict__ ek, const uint8_t* __restrict__ m, uint8_t* __restrict__ c, uint8_t* __restrict__ Kout,
                  unsigned long long* stamps) {
     __shared__ K2Lds<K + 1> xl;
     __shared__ SmallHand<K, ETA1> hand;
-    __shared__ uint32_t sq[SMALL_WAVES][XOF_LDS_WORDS];
-    __shared__ uint2 rc_tables[SMALL_WAVES][WK_RC_ENTRIES];
+    __shared__ uint32_t sq[NW][XOF_LDS_WORDS];
+    __shared__ uint2 rc_tables[NW][WK_RC_ENTRIES];
+    __shared__ uint32_t next_job;
     constexpr unsigned EK = 384 * K + 32, PS = (ETA1 == 3) ? 192 : 128;
     const int wv = wave_id();
     unsigned long long* st = stamps + 32 * wv;
     stamp(st, 0);
     WkLane cst;
     wk_lane_init(cst, rc_tables[wave_id()]);
+    if (threadIdx.x == 0) next_job = 0;
+    block_barrier();
     stamp(st, 1);
     if (wv == 0) {
         const int i = wk_index();
@@ -43,14 +46,13 @@ k_encaps_stamped(const uint8_t* __restrict__ ek, const uint8_t* __restrict__ m, 
         if (wk_primary() && i < 4) reinterpret_cast<uint2*>(Kout)[i] = o;
         else if (wk_primary() && i < 8) reinterpret_cast<uint2*>(hand.r)[i - 4] = o;
         stamp(st, 3);
-    } else {
-        for (int s = wv - 1; s < K * K; s += SMALL_WAVES - 1)
-            wk_sample_ntt(cst, ek + 384 * K, (unsigned)(s / K), (unsigned)(s % K), hand.A + s * 256, sq[wv]);
-        stamp(st, 3);
     }
+    for (unsigned s; (s = take_job(&next_job)) < (unsigned)(K * K);)
+        wk_sample_ntt(cst, ek + 384 * K, s / K, s % K, hand.A + s * 256, sq[wv]);
+    stamp(st, 9);
     block_barrier();
     stamp(st, 4);
-    for (int j = wv; j < 2 * K + 1; j += SMALL_WAVES)
+    for (int j = wv; j < 2 * K + 1; j += NW)
         wk_prf(cst, hand.r, (unsigned)j, j < K ? (unsigned)ETA1 : 2u, 168u, hand.prf + j * PS);
     stamp(st, 5);
     block_barrier();
@@ -64,7 +66,7 @@ k_encaps_stamped(const uint8_t* __restrict__ ek, const uint8_t* __restrict__ m, 
     }
 }
 
-int main() {
+template <int NW> int run() {
     constexpr int K = 3;
     std::vector<uint8_t> ek(1184), m(32), c(1088), Kk(32);
     for (size_t i = 0; i < ek.size(); i++) ek[i] = (uint8_t)(i * 7 + 1);
@@ -74,22 +76,25 @@ int main() {
     unsigned long long* ds;
     (void)hipMalloc(&dek, 1184); (void)hipMalloc(&dm, 32); (void)hipMalloc(&dc, 1088); (void)hipMalloc(&dK, 32); (void)hipMalloc(&ds, 8 * 32 * 8);
     (void)hipMemcpy(dek, ek.data(), 1184, hipMemcpyHostToDevice); (void)hipMemcpy(dm, m.data(), 32, hipMemcpyHostToDevice);
-    unsigned long long h[8 * 32];
+    unsigned long long h[8 * 32] = {0};
     double acc[10] = {0}, accr[10] = {0}, xof_done = 0;
     const int R = 200;
     for (int r = 0; r < R + 20; r++) {
-        k_encaps_stamped<3, 2, 10, 4><<<1, WAVE * SMALL_WAVES>>>(dek, dm, dc, dK, ds);
+        k_encaps_stamped<3, 2, 10, 4, NW><<<1, WAVE * NW>>>(dek, dm, dc, dK, ds);
         (void)hipDeviceSynchronize();
         if (r < 20) continue;
         (void)hipMemcpy(h, ds, sizeof h, hipMemcpyDeviceToHost);
-        for (int k = 1; k <= 8; k++) { acc[k] += (double)(h[2 * k] - h[2 * (k - 1)]); accr[k] += (double)(h[2 * k + 1] - h[2 * (k - 1) + 1]); }
+        for (int k = 1; k <= 8; k++) {
+            if (k == 4) { acc[k] += (double)(h[2 * 4] - h[2 * 3]); accr[k] += (double)(h[2 * 4 + 1] - h[2 * 3 + 1]); continue; }
+            acc[k] += (double)(h[2 * k] - h[2 * (k - 1)]); accr[k] += (double)(h[2 * k + 1] - h[2 * (k - 1) + 1]);
+        }
         unsigned long long last = 0;
-        for (int w = 1; w < 8; w++) last = h[32 * w + 2 * 3 + 1] > last ? h[32 * w + 2 * 3 + 1] : last;   // realtime stamp 3 of the XOF waves
+        for (int w = 0; w < NW; w++) last = h[32 * w + 2 * 9 + 1] > last ? h[32 * w + 2 * 9 + 1] : last;   // realtime stamp 9: a wave found no SampleNTT entry left
         xof_done += (double)(last - h[1]);
     }
-    const char* name[9] = {"", "lane constants + iota table", "H(ek): 9 blocks absorbed (9 permutations)", "G(m || h) + stores", "barrier 1 (wave 0 waits for SampleNTT)",
+    const char* name[9] = {"", "lane constants + iota table", "H(ek): 9 blocks absorbed (9 permutations)", "G(m || h) + stores", "SampleNTT entries wave 0 took + barrier 1",
                            "PRF (1 permutation) + its stores to LDS", "barrier 2", "K-PKE.Encrypt (encrypt1_body)", "outstanding stores drained"};
-    printf("k_encaps_small<3> stage by stage, wave 0 of a lone workgroup, mean of %d launches (shader cycles ; us by the 100 MHz clock)\n", R);
+    printf("k_encaps_small<3, ..., %d waves> stage by stage, wave 0 of a lone workgroup, mean of %d launches (shader cycles ; us by the 100 MHz clock)\n", NW, R);
     double tc = 0, tr = 0;
     for (int k = 1; k <= 8; k++) { printf("  %-48s %9.0f cycles  %6.2f us\n", name[k], acc[k] / R, accr[k] / R / 100.0); tc += acc[k]; tr += accr[k]; }
     printf("  %-48s %9.0f cycles  %6.2f us   (clock %.0f MHz)\n", "total", tc / R, tr / R / 100.0, tc / tr * 100.0);
@@ -97,3 +102,4 @@ int main() {
            (accr[1] + accr[2] + accr[3]) / R / 100.0);
     return 0;
 }
+int main() { run<SMALL_WAVES>(); run<SMALL_WAVES_DENSE>(); return 0; }
