@@ -44,6 +44,8 @@ timeout -k 10 400 bash tools/batch_sweep.sh > "$OUT/batch_sweep.txt" 2>/dev/null
 timeout -k 10 400 bash tools/small_sweep.sh > "$OUT/small_sweep.txt" 2>/dev/null || { echo "FAILED small_sweep" >&2; exit 1; }
 timeout -k 10 100 python3 tools/keygen_latency.py 2>/dev/null | grep keygen > "$OUT/keygen_latency.txt" || { echo "FAILED keygen_latency" >&2; exit 1; }
 timeout -k 10 100 ./tools/keccak_wave_ubench.bin > "$OUT/keccak_wave_ubench.txt" 2>&1 || { echo "FAILED keccak_wave_ubench" >&2; exit 1; }
+timeout -k 10 100 ./tools/small_stamps.bin > "$OUT/small_stamps.txt" 2>&1 || { echo "FAILED small_stamps" >&2; exit 1; }
+timeout -k 10 100 ./tools/host_path_breakdown.bin > "$OUT/host_path_breakdown.txt" 2>&1 || { echo "FAILED host_path_breakdown" >&2; exit 1; }
 timeout -k 10 300 python3 tools/energy_probe.py 2>/dev/null > "$OUT/energy.txt" || { echo "FAILED energy_probe" >&2; exit 1; }
 timeout -k 10 600 python3 -m pytest tests -m gpu -q 2>&1 | tail -3 > "$OUT/gpu_tier.log" || { echo "FAILED gpu tier" >&2; cat "$OUT/gpu_tier.log" >&2; exit 1; }
 fi
@@ -60,6 +62,8 @@ for wl in kem768 ntt kem1024; do
     run sq_$wl --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_LDS SQ_INSTS_SALU GRBM_GUI_ACTIVE \
         --kernel-trace --output-format csv -d "$OUT/sq_$wl" -o $wl -- python3 "$ROOT/bench.py" --workload $wl --no-cpu --no-also --steps 3 --warmup 1 || exit 1
 done
+bash "$ROOT/tools/small_profile.sh" > /dev/null || { echo "FAILED small_profile" >&2; exit 1; }
+cp "$ROOT/gpurun_out/prof_small/summary.txt" "$OUT/small_kernel_stats.txt"
 find "$OUT" -name '*_kernel_trace.csv' -delete     # the per-dispatch traces are not used (stats + counter_collection are) and would not fit the 64 MiB that travel back
 find "$OUT" -name '*.csv' | sed "s|$ROOT/||" | sort
 du -sh "$OUT"

@@ -34,6 +34,9 @@ cp $D/small_sweep.txt profiles/${T}_small_sweep.txt
 cp $D/keygen_latency.txt profiles/${T}_keygen_latency.txt
 cp $D/keccak_wave_ubench.txt profiles/${T}_keccak_wave_ubench.txt
 cp $D/energy.txt profiles/${T}_energy.txt
+cp $D/small_stamps.txt profiles/${T}_small_stamps.txt
+cp $D/host_path_breakdown.txt profiles/${T}_host_path_breakdown.txt
+cp $D/small_kernel_stats.txt profiles/${T}_small_kernel_stats.txt
 cp $D/gpu_tier.log profiles/${T}_gpu_tier.log
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -S --cuda-device-only -o /tmp/capi_floor.s crystals-kyber_amd/csrc/mlkem_capi.hip 2>/dev/null && \
   python tools/isa_floor.py /tmp/capi_floor.s --out profiles/${T}_isa_floor.json > /dev/null || exit 1

@@ -1,12 +1,12 @@
 #!/bin/bash
 # tools/small_profile.sh — rocprofv3 evidence for the small-call kernels (mlkem_small.hpp): kernel-trace stats of Encaps + Decaps at
-# 1, 64 and 512 items per call (bench.py --batch N), and an SQ pass at 64 items (waves, VALU / LDS instructions, waiting).
+# 1, 64, 512 and 768 items per call (bench.py --batch N), and an SQ pass at 64 items (waves, VALU / LDS instructions, waiting).
 # Output: gpurun_out/prof_small/ ; summaries go to profiles/r04_small_kernel_stats.txt.
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/prof_small
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-for n in 1 64 512; do
+for n in 1 64 512 768; do
   timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_$n -o s -- python3 $ROOT/bench.py --batch $n --steps 300 --warmup 10 --no-cpu --no-also > $OUT/kt_$n.log 2>&1 || { echo FAILED kt_$n; exit 1; }
 done
 timeout -k 10 200 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --kernel-trace --output-format csv \
@@ -15,7 +15,7 @@ find $OUT -name '*_kernel_trace.csv' -delete
 cd $ROOT
 {
   echo "Small-call kernels under rocprofv3 (tools/small_profile.sh): ML-KEM-768 Encaps + Decaps of N items per call, 310 calls each."
-  for n in 1 64 512; do
+  for n in 1 64 512 768; do
     echo "== N = $n: --kernel-trace --stats (name, calls, average ns, min, max)"
     python3 - $OUT/kt_$n/s_kernel_stats.csv <<'P'
 import csv, sys
