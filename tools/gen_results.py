@@ -217,7 +217,10 @@ def main():
         L.append("")
     for name, title in (("soak.txt", "Sustained run (`tools/soak.py`)"),
                         ("small_kernel_stats.txt", "Small-call kernels under rocprofv3 (`tools/small_profile.sh`)"),
-                        ("small_sweep.txt", "Small calls: one workgroup per item against the batch path (`tools/small_sweep.sh`)"),
+                        ("small_stamps.txt", "Where a one-item Encaps spends its time, stage by stage (`tools/small_stamps.hip`)"),
+                        ("keygen_latency.txt", "Device-resident call latency per parameter set and operation (`tools/keygen_latency.py`)"),
+                        ("host_path_breakdown.txt", "Host-pointer call of one item from C: launch floor, device buffers, host buffers (`tools/host_path_breakdown.hip`)"),
+                        ("small_sweep.txt", "Small calls: one workgroup per item (eight / four waves) against the batch path (`tools/small_sweep.sh`)"),
                         ("energy.txt", "Energy by kernel family, each looped alone at its 2^20 shapes (`tools/energy_probe.py`)"),
                         ("keccak_wave_ubench.txt", "Keccak-f[1600] of a lone wave: lane-sliced / half-wave (round 3) / wave-wide (`tools/keccak_wave_ubench.hip`)")):
         path = os.path.join(P, "%s_%s" % (TAG, name))

@@ -42,7 +42,7 @@ timeout -k 10 400 python3 tools/stream_bench.py 2>/dev/null | grep '^{' | tail -
 timeout -k 10 400 bash tools/batch_sweep.sh > "$OUT/batch_sweep.txt" 2>/dev/null || { echo "FAILED batch_sweep" >&2; exit 1; }
 # round 4: small calls (one workgroup per item against the batch path), KeyGen latency, the wave-wide Keccak, energy by kernel family
 timeout -k 10 400 bash tools/small_sweep.sh > "$OUT/small_sweep.txt" 2>/dev/null || { echo "FAILED small_sweep" >&2; exit 1; }
-timeout -k 10 100 python3 tools/keygen_latency.py 2>/dev/null | grep keygen > "$OUT/keygen_latency.txt" || { echo "FAILED keygen_latency" >&2; exit 1; }
+timeout -k 10 100 python3 tools/keygen_latency.py 2>/dev/null | grep "per call" > "$OUT/keygen_latency.txt" || { echo "FAILED keygen_latency" >&2; exit 1; }
 timeout -k 10 100 ./tools/keccak_wave_ubench.bin > "$OUT/keccak_wave_ubench.txt" 2>&1 || { echo "FAILED keccak_wave_ubench" >&2; exit 1; }
 timeout -k 10 100 ./tools/small_stamps.bin > "$OUT/small_stamps.txt" 2>&1 || { echo "FAILED small_stamps" >&2; exit 1; }
 timeout -k 10 100 ./tools/host_path_breakdown.bin > "$OUT/host_path_breakdown.txt" 2>&1 || { echo "FAILED host_path_breakdown" >&2; exit 1; }
