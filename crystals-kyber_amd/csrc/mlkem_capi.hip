@@ -176,6 +176,10 @@ int mlkem_ctx_create(mlkem_ctx** out, int device, size_t chunk_items) {
         long long v = atoll(e);
         if (v >= 0) c->ws.small_max = (size_t)v;
     }
+    if (const char* e = getenv("MLKEM_SMALL_WIDE_ITEMS")) {      // Decaps calls up to this size: twelve waves per item (k >= 3)
+        long long v = atoll(e);
+        if (v >= 0) c->ws.small_wide_max = (size_t)v;
+    }
     if (const char* e = getenv("MLKEM_SMALL_LATENCY_ITEMS")) {   // small calls above this size: four waves per item instead of eight
         long long v = atoll(e);
         if (v >= 0) c->ws.small_lat_max = (size_t)v;

@@ -209,6 +209,37 @@ __device__ __forceinline__ int lane_id_fresh() {
 #endif
     return l;
 }
+// Hand-over between the waves of ONE workgroup through a counter in LDS, for stages that not every wave takes part in (a workgroup
+// barrier would make all of them wait for the slowest): the producer's earlier writes (LDS or global) are visible to a wave that
+// has seen the counter reach its value.  Waves of a workgroup are co-resident, so a waiting wave cannot keep its producer from running.
+__device__ __forceinline__ void flag_signal(uint32_t* flag) {
+#ifdef MLKEM_EMU
+    emu::wave_barrier();
+    if ((threadIdx.x & 63) == 0) __atomic_fetch_add(flag, 1u, __ATOMIC_SEQ_CST);
+    emu::wave_barrier();
+#else
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    // lane_id_fresh(): the condition must not be a loop invariant the compiler can see.  With `lane_id() == 0` here and in take_job
+    // the job loop was unswitched on it -- lane 0 and lanes 1..63 of ONE wave in two copies of the loop -- and the copy without
+    // lane 0 read job number 0 from readfirstlane for ever (the first GPU run of this code hung; the emulator cannot show it)
+    if (lane_id_fresh() == 0) __hip_atomic_fetch_add(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
+}
+__device__ __forceinline__ void flag_wait(const uint32_t* flag, uint32_t want) {
+#ifdef MLKEM_EMU
+    while (__atomic_load_n(flag, __ATOMIC_SEQ_CST) < want) sched_yield();
+    emu::wave_barrier();
+#else
+    // the value is read into an SGPR (wave-uniform: a scalar loop); the poll count is bounded so that a logic error ends in a trap
+    // (the call fails) instead of a wave that never finishes
+    unsigned polls = 0;
+    while ((uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < want) {
+        __builtin_amdgcn_s_sleep(4);
+        if (++polls > (1u << 22)) __builtin_trap();
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#endif
+}
 // Order wave-private LDS traffic between lanes of ONE wave (DS ops of a wave execute in issue order;
 // this only stops the compiler from moving them).
 __device__ __forceinline__ void wave_lds_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); }

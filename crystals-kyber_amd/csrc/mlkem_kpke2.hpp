@@ -643,7 +643,8 @@ template <int K, int ETA1, int DU, int DV, bool COMPARE>
 __device__ __forceinline__ void
 encrypt1_body(float2 (*xch)[2][128], const uint8_t* __restrict__ ek, const uint8_t* __restrict__ msg, const uint16_t* __restrict__ A,
               const uint8_t* __restrict__ prf, uint8_t* __restrict__ c_out, const uint8_t* __restrict__ c_in, const uint8_t* __restrict__ Kp,
-              const uint8_t* __restrict__ Kbar, uint8_t* __restrict__ Kout, int32_t* __restrict__ mod_status) {
+              const uint8_t* Kbar, uint8_t* __restrict__ Kout, int32_t* __restrict__ mod_status,
+              const uint32_t* kbar_flag = nullptr) {   // kbar_flag: counter in LDS that reaches 1 once Kbar is written (hence Kbar not __restrict__)
     const int l = lane_id(), h = l >> 5, t = l & 31, nb = k2_blk(t);
     constexpr unsigned PS = (ETA1 == 3) ? 192 : 128;
     constexpr int NG = K + 1, NL = (NG + 1) / 2;       // rows in all, rows per half
@@ -748,6 +749,7 @@ encrypt1_body(float2 (*xch)[2][128], const uint8_t* __restrict__ ek, const uint8
     if constexpr (COMPARE) {
         // both candidates are read and blended by mask: neither a branch nor an address depends on whether the ciphertext matched
         const uint32_t reject = __ballot(diff != 0) != 0 ? 0xFFFFFFFFu : 0u;
+        if (kbar_flag) flag_wait(kbar_flag, 1u);
         if (l < 8) {
             const uint32_t kp = reinterpret_cast<const uint32_t*>(Kp)[l];
             const uint32_t kb = reinterpret_cast<const uint32_t*>(Kbar)[l];

@@ -120,6 +120,7 @@ struct Workspace {
     size_t small_lat_max = 320;   // ... of which calls of at most this many items use eight waves per item (shortest chain: 0.070
                                   // against 0.083 ms per pair at one item, 0.077 against 0.095 at 256), larger ones four (twice the
                                   // items per CU: 0.115 against 0.117 at 384, 0.160 against 0.183 at 768); env MLKEM_SMALL_LATENCY_ITEMS
+    size_t small_wide_max = 128;  // ... and Decaps calls of at most this many items twelve (k >= 3); env MLKEM_SMALL_WIDE_ITEMS
     // measurement aid (mlkem_ctx_debug_stages, tools/energy_probe.py): which kernel families the batch path launches; the
     // outputs of a call with stages missing are meaningless.  1 = hash kernels, 2 = sampler, 4 = K-PKE.Encrypt / KeyGen, 8 = Decrypt
     unsigned stages = 15;
@@ -328,7 +329,8 @@ inline void decaps_run(stream_t st, const ParamSet& p, size_t n, const uint8_t* 
         const int rate = ws.fips ? 136 : 168;
         int32_t* sts = hash_check ? status : (int32_t*)nullptr;
 #define MLKEM_DS(HC, JR, NW) launch("k_decaps_small", k_decaps_small<K, ETA1, DU, DV, HC, JR, NW>, (HC) ? 2 * n : n, WAVE * NW, st, n, dk, c, Kout, sts, rate)
-#define MLKEM_DS2(HC, JR) do { if (n <= ws.small_lat_max) MLKEM_DS(HC, JR, SMALL_WAVES); else MLKEM_DS(HC, JR, SMALL_WAVES_DENSE); } while (0)
+        constexpr int LW = K >= 3 ? SMALL_WAVES_WIDE : SMALL_WAVES;   // k^2 = 9 / 16 SampleNTT jobs: twelve waves while a workgroup has a CU to itself
+#define MLKEM_DS2(HC, JR) do { if (n <= ws.small_wide_max) MLKEM_DS(HC, JR, LW); else if (n <= ws.small_lat_max) MLKEM_DS(HC, JR, SMALL_WAVES); else MLKEM_DS(HC, JR, SMALL_WAVES_DENSE); } while (0)
         if (hash_check && !ws.fips) MLKEM_DS2(true, 168);
         else if (!ws.fips) MLKEM_DS2(false, 168);
         else if (hash_check) MLKEM_DS2(true, 136);

@@ -3,19 +3,23 @@
 // A call of one to a few hundred items -- every call of the ml_kem.h drop-in API -- cannot fill the GPU; its time is the
 // length of its dependency chain: H(ek) (9 sequential permutations at k = 3) -> G -> PRF -> Encrypt for Encaps.  The batch path
 // spreads that chain over four kernels on two streams (lane-sliced or wave-wide sponges, sampler, arithmetic) and pays a launch
-// gap between each.  Here the item's whole operation is one workgroup of SMALL_WAVES wavefronts that run the item's
-// independent sponges SIDE BY SIDE, each on the one-sponge-per-wave Keccak of mlkem_wkeccak.hpp (3.5 us per permutation for a
-// lone wave instead of 8.8 lane-sliced), meet at workgroup barriers, and hand the sampled matrix and the PRF rows to the
+// gap between each.  Here the item's whole operation is one workgroup of 4, 8 or 12 wavefronts that run the item's
+// independent sponges SIDE BY SIDE, each on the one-sponge-per-wave Keccak of mlkem_wkeccak.hpp (2.6 us per permutation for a
+// lone wave instead of 8.8 lane-sliced), and hand the sampled matrix and the PRF rows to the
 // arithmetic (keygen2_body / decrypt4_body as the batch kernels run them; encrypt1_body, where the two half-waves share the item's
 // k + 1 output rows) through LDS (SmallHand):
-//   k_encaps_small  stage 1: wave 0: h = H(ek), (K, r) = G(m || h)        | waves 1..: A-hat^T = SampleNTT(rho || j || i)
-//                   stage 2: all waves: PRF(r, n), n = 0..2k
-//                   stage 3: wave 0: K-PKE.Encrypt                                            (ml_kem.c:1093-1130, :776-936)
-//   k_decaps_small  stage 1: wave 0: m' = K-PKE.Decrypt, (K', r') = G(m' || h) | wave 1: Kbar = J(z || c) | waves 2..: A-hat^T
-//                            (status = H(dk.ek) == dk.h ? 0 : -5 in a workgroup of its own: nothing else waits for that chain)
-//                   stage 2: PRF(r', n) ; stage 3: wave 0: c' = Encrypt, K = c == c' ? K' : Kbar   (ml_kem.c:1310-1359, :1136-1225)
-//   k_keygen_small  stage 1: wave 0: (rho, sigma) = G(d || k) ; stage 2: all waves: A-hat and the 2k PRF rows
-//                   stage 3: wave 0: K-PKE.KeyGen, then H(ek) and the dk tail                 (ml_kem.c:1034-1084, :651-769)
+//   k_encaps_small  wave 0: h = H(ek), (K, r) = G(m || h), r_ready | every wave, when it has nothing else to do: jobs = the k^2
+//                   SampleNTT(rho || j || i), then the 2k + 1 PRF(r, n) (these wait for r_ready) | wave 0, when all jobs are
+//                   done: K-PKE.Encrypt                                                       (ml_kem.c:1093-1130, :776-936)
+//   k_decaps_small  wave 0: m' = K-PKE.Decrypt, (K', r') = G(m' || h), r_ready | wave 1: Kbar = J(z || c), kbar_ready | jobs as
+//                   above | wave 0: c' = Encrypt, then -- waiting for kbar_ready only here -- K = c == c' ? K' : Kbar
+//                   (status = H(dk.ek) == dk.h ? 0 : -5 in a workgroup of its own: nothing else waits for that chain)
+//                                                                                             (ml_kem.c:1310-1359, :1136-1225)
+//   k_keygen_small  wave 0: (rho, sigma) = G(d || k) ; barrier ; jobs: A-hat and the 2k PRF rows ; barrier ;
+//                   wave 0: K-PKE.KeyGen, then H(ek) and the dk tail                          (ml_kem.c:1034-1084, :651-769)
+// Hand-overs are counters in LDS (flag_signal / flag_wait, mlkem_device.hpp), not workgroup barriers: Encaps and Decaps have one
+// barrier, right after the counters are zeroed.  A barrier makes every wave wait for the slowest; here only the consumer of a value
+// waits for its producer, so that J (7 permutations at k = 3, needed by the last instruction of Decaps) delays nothing.
 // SampleNTT on a wave: the squeezed block (168 bytes in 21 SIMD lanes) goes through 176 bytes of LDS so that SIMD lane t
 // reads triple t (ml_kem.c:208-219: 3 bytes -> two 12-bit candidates); the accepted candidates of the 56 lanes are put in order
 // with two ballots and a prefix count and stored straight to the polynomial.  The triple limit and the seed-mutation retry of
@@ -32,13 +36,19 @@ namespace mlkem {
 // run on seven waves while wave 0 walks H(ek).  4 is the dense form for calls that fill the chip: half the registers per item,
 // so twice the items per CU, and the item's sponges are dealt out by a counter in LDS (take_job) so that the waves of the serial
 // roles join the sampling when they are through -- four waves then finish about when wave 0's chain does.
-constexpr int SMALL_WAVES = 8, SMALL_WAVES_DENSE = 4;
+constexpr int SMALL_WAVES = 8, SMALL_WAVES_DENSE = 4, SMALL_WAVES_WIDE = 12;
 
 // The next job number of the workgroup's counter (0, 1, 2, ... in the order the waves ask), the same value in all lanes.
+// (readfirstlane: the compiler must KNOW the number is wave-uniform, or it wraps the job loop -- ballots, shuffles and spin-waits
+// inside -- into EXEC-mask bookkeeping for a divergence that never happens)
 __device__ __forceinline__ unsigned take_job(uint32_t* counter) {
     unsigned j = 0;
-    if (lane_id() == 0) j = atomicAdd(counter, 1u);
+    if (lane_id_fresh() == 0) j = atomicAdd(counter, 1u);   // _fresh: see flag_signal
+#ifdef MLKEM_EMU
     return (unsigned)__shfl((int)j, 0);
+#else
+    return (unsigned)__builtin_amdgcn_readfirstlane((int)j);
+#endif
 }
 
 #ifdef MLKEM_EMU
@@ -208,6 +218,34 @@ struct __attribute__((aligned(16))) SmallHand {
     uint8_t r[32], m[32], Kp[32], Kbar[32], rho[32];
 };
 
+// The workgroup's hand-over counters (flag_signal / flag_wait, mlkem_device.hpp).  Only wave 0 runs an operation from end to end;
+// the others take jobs (take_job) and leave, so after the first barrier nothing makes every wave wait for the slowest one.
+struct SmallSync {
+    uint32_t next_job;     // next job to hand out
+    uint32_t jobs_done;    // jobs finished (their outputs are in SmallHand)
+    uint32_t r_ready;      // 1: the 32-byte PRF key (r / r' / sigma) is in SmallHand
+    uint32_t kbar_ready;   // 1: Decaps' K-bar = J(z || c) is in SmallHand
+};
+
+// The job loop every wave of an item's workgroup runs when it has nothing else to do: jobs 0 .. k^2 - 1 are the matrix entries
+// (entry s = SampleNTT(rho || s / k || s % k) at A + 256 s with `transpose`, rho || s % k || s / k without), the next `rows` jobs
+// the PRF rows (counter n = row; eta1 for n < k, ETA_REST after), which need the key behind sy.r_ready.
+template <int K, int ETA1, int ETA_REST = 2>
+__device__ __forceinline__ void small_jobs(SmallSync& sy, const WkLane& cst, const uint8_t* rho, bool transpose, uint16_t* A, const uint8_t* key,
+                                           uint8_t* prf, int rows, unsigned prf_rate, uint32_t* sq) {
+    constexpr unsigned PS = (ETA1 == 3) ? 192 : 128;
+    for (unsigned j; (j = take_job(&sy.next_job)) < (unsigned)(K * K + rows);) {
+        if (j < (unsigned)(K * K)) {
+            wk_sample_ntt(cst, rho, transpose ? j / K : j % K, transpose ? j % K : j / K, A + j * 256, sq);
+        } else {
+            const unsigned row = j - K * K;
+            flag_wait(&sy.r_ready, 1u);
+            wk_prf(cst, key, row, row < (unsigned)K ? (unsigned)ETA1 : (unsigned)ETA_REST, prf_rate, prf + row * PS);
+        }
+        flag_signal(&sy.jobs_done);
+    }
+}
+
 // H(msg) for a message of `len` bytes (multiple of 8) at `msg`: digest in Keccak lanes 0..3 of `a`
 __device__ __forceinline__ void wk_H(WkState& a, const WkLane& c, const uint8_t* msg, unsigned len) {
     wk_absorb<136, 0x06>(a, c, msg, len, msg, len);
@@ -224,8 +262,8 @@ k_encaps_small(size_t n, const uint8_t* __restrict__ ek, const uint8_t* __restri
     __shared__ SmallHand<K, ETA1> hand;
     __shared__ uint32_t sq[NW][XOF_LDS_WORDS];
     __shared__ uint2 rc_tables[NW][WK_RC_ENTRIES];
-    __shared__ uint32_t next_job;
-    constexpr unsigned EK = 384 * K + 32, PS = (ETA1 == 3) ? 192 : 128, CLEN = 32 * (DU * K + DV);
+    __shared__ SmallSync sy;
+    constexpr unsigned EK = 384 * K + 32, CLEN = 32 * (DU * K + DV);
     const int wv = wave_id();
     const size_t item = blockIdx.x;
     if (item >= n) return;
@@ -234,7 +272,7 @@ k_encaps_small(size_t n, const uint8_t* __restrict__ ek, const uint8_t* __restri
     uint8_t *my_prf = hand.prf, *my_r = hand.r;
     WkLane cst;
     wk_lane_init(cst, rc_tables[wave_id()]);
-    if (threadIdx.x == 0) next_job = 0;
+    if (threadIdx.x == 0) { sy.next_job = 0; sy.jobs_done = 0; sy.r_ready = 0; sy.kbar_ready = 0; }
     block_barrier();
     if (wv == 0) {                                   // h = H(ek) ; (K, r) = G(m || h)
         const int i = wk_index();
@@ -248,17 +286,14 @@ k_encaps_small(size_t n, const uint8_t* __restrict__ ek, const uint8_t* __restri
         o.x = a.lo; o.y = a.hi;
         if (wk_primary() && i < 4) reinterpret_cast<uint2*>(Kout + item * 32)[i] = o;
         else if (wk_primary() && i < 8) reinterpret_cast<uint2*>(my_r)[i - 4] = o;
+        flag_signal(&sy.r_ready);
     }
-    // A-hat^T[a][b] = SampleNTT(rho || a || b)   (ml_kem.c:817-823): whichever wave is free takes the next entry
-    for (unsigned s; (s = take_job(&next_job)) < (unsigned)(K * K);)
-        wk_sample_ntt(cst, my_ek + 384 * K, s / K, s % K, my_A + s * 256, sq[wv]);
-    block_barrier();
-    for (int j = wv; j < 2 * K + 1; j += NW)
-        wk_prf(cst, my_r, (unsigned)j, j < K ? (unsigned)ETA1 : 2u, (unsigned)prf_rate, my_prf + j * PS);
-    block_barrier();
-    if (wv == 0)
-        encrypt1_body<K, ETA1, DU, DV, false>(xl.xch, my_ek, m + item * 32, my_A, my_prf, c + item * CLEN, nullptr, nullptr, nullptr, nullptr,
-                                              mod_status ? mod_status + item : nullptr);
+    // jobs 0 .. k^2 - 1: A-hat^T[a][b] = SampleNTT(rho || a || b) (ml_kem.c:817-823) ; then the 2k + 1 PRF rows, which wait for r
+    small_jobs<K, ETA1>(sy, cst, my_ek + 384 * K, /*transpose=*/true, my_A, my_r, my_prf, 2 * K + 1, (unsigned)prf_rate, sq[wv]);
+    if (wv != 0) return;
+    flag_wait(&sy.jobs_done, (uint32_t)(K * K + 2 * K + 1));
+    encrypt1_body<K, ETA1, DU, DV, false>(xl.xch, my_ek, m + item * 32, my_A, my_prf, c + item * CLEN, nullptr, nullptr, nullptr, nullptr,
+                                          mod_status ? mod_status + item : nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -272,8 +307,8 @@ k_decaps_small(size_t n, const uint8_t* __restrict__ dk, const uint8_t* __restri
     __shared__ SmallHand<K, ETA1> hand;
     __shared__ uint32_t sq[NW][XOF_LDS_WORDS];
     __shared__ uint2 rc_tables[NW][WK_RC_ENTRIES];
-    __shared__ uint32_t next_job;
-    constexpr unsigned EK = 384 * K + 32, DK = 768 * K + 96, PS = (ETA1 == 3) ? 192 : 128, CLEN = 32 * (DU * K + DV);
+    __shared__ SmallSync sy;
+    constexpr unsigned EK = 384 * K + 32, DK = 768 * K + 96, CLEN = 32 * (DU * K + DV);
     const int wv = wave_id();
     // KEM_Decaps' check of the stored H(ek) (9 permutations at k = 3: the longest chain of the operation, and nothing but the
     // status depends on it) runs in workgroups of its own, one live wave each.  They are blocks [0, n): dispatched first, they
@@ -301,7 +336,7 @@ k_decaps_small(size_t n, const uint8_t* __restrict__ dk, const uint8_t* __restri
         if (lane_id() == 0 && status) status[item] = bad ? -5 : 0;
         return;
     }
-    if (threadIdx.x == 0) next_job = 0;
+    if (threadIdx.x == 0) { sy.next_job = 0; sy.jobs_done = 0; sy.r_ready = 0; sy.kbar_ready = 0; }
     block_barrier();
     if (wv == 0) {                                   // m' = K-PKE.Decrypt(dk_pke, c) ; (K', r') = G(m' || h)
         decrypt4_body<K, DU, DV>(0, 1, my_dk, (size_t)DK, my_c, my_m);
@@ -319,22 +354,21 @@ k_decaps_small(size_t n, const uint8_t* __restrict__ dk, const uint8_t* __restri
         if (prim && i < 4) reinterpret_cast<uint2*>(my_Kp)[i] = o;
         else if (prim && i < 8) reinterpret_cast<uint2*>(my_r)[i - 4] = o;
         if (!HASH_CHECK && lane_id() == 0 && status) status[item] = 0;
-    } else if (wv == 1) {                            // Kbar = J(z || c)
+        flag_signal(&sy.r_ready);
+    } else if (wv == 1) {                            // Kbar = J(z || c): only the final select waits for it
         WkState a;
         wk_absorb<JRATE, 0x1F>(a, cst, my_dk + 768 * K + 64, 32, my_c, 32 + CLEN);
         uint2 o;
         o.x = a.lo; o.y = a.hi;
         if (prim && i < 4) reinterpret_cast<uint2*>(my_Kbar)[i] = o;
+        flag_signal(&sy.kbar_ready);
     }
-    // A-hat^T of the re-encryption (rho sits in dk.ek): whichever wave is free takes the next entry
-    for (unsigned s; (s = take_job(&next_job)) < (unsigned)(K * K);)
-        wk_sample_ntt(cst, my_dk + 768 * K, s / K, s % K, my_A + s * 256, sq[wv]);
-    block_barrier();
-    for (int j = wv; j < 2 * K + 1; j += NW)
-        wk_prf(cst, my_r, (unsigned)j, j < K ? (unsigned)ETA1 : 2u, (unsigned)prf_rate, my_prf + j * PS);
-    block_barrier();
-    if (wv == 0)
-        encrypt1_body<K, ETA1, DU, DV, true>(xl.xch, my_dk + 384 * K, my_m, my_A, my_prf, nullptr, my_c, my_Kp, my_Kbar, Kout + item * 32, nullptr);
+    // jobs: A-hat^T of the re-encryption (rho sits in dk.ek), then the 2k + 1 PRF rows, which wait for r'
+    small_jobs<K, ETA1>(sy, cst, my_dk + 768 * K, /*transpose=*/true, my_A, my_r, my_prf, 2 * K + 1, (unsigned)prf_rate, sq[wv]);
+    if (wv != 0) return;
+    flag_wait(&sy.jobs_done, (uint32_t)(K * K + 2 * K + 1));
+    encrypt1_body<K, ETA1, DU, DV, true>(xl.xch, my_dk + 384 * K, my_m, my_A, my_prf, nullptr, my_c, my_Kp, my_Kbar, Kout + item * 32, nullptr,
+                                         &sy.kbar_ready);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -347,8 +381,8 @@ k_keygen_small(size_t n, const uint8_t* __restrict__ d, const uint8_t* __restric
     __shared__ SmallHand<K, ETA1> hand;          // prf: 2k rows of it ; r: sigma
     __shared__ uint32_t sq[NW][XOF_LDS_WORDS];
     __shared__ uint2 rc_tables[NW][WK_RC_ENTRIES];
-    __shared__ uint32_t next_job;
-    constexpr unsigned EK = 384 * K + 32, DK = KEM_DK ? 768 * K + 96 : 384 * K, PS = (ETA1 == 3) ? 192 : 128;
+    __shared__ SmallSync sy;
+    constexpr unsigned EK = 384 * K + 32, DK = KEM_DK ? 768 * K + 96 : 384 * K;
     const int wv = wave_id();
     const size_t item = blockIdx.x;
     if (item >= n) return;
@@ -374,14 +408,11 @@ k_keygen_small(size_t n, const uint8_t* __restrict__ d, const uint8_t* __restric
         if (prim && i < 4) reinterpret_cast<uint2*>(my_rho)[i] = o;
         else if (prim && i < 8) reinterpret_cast<uint2*>(my_sigma)[i - 4] = o;
     }
-    if (threadIdx.x == 0) next_job = 0;
+    if (threadIdx.x == 0) { sy.next_job = 0; sy.jobs_done = 0; sy.r_ready = 1; sy.kbar_ready = 0; }   // sigma is ready behind the barrier
     block_barrier();
     // A-hat[a][b] = SampleNTT(rho || b || a) (ml_kem.c:686-693) and the 2k PRF rows (s: n = 0..k-1, e: n = k..2k-1, all eta1),
     // dealt out longest first
-    for (unsigned j; (j = take_job(&next_job)) < (unsigned)(K * K + 2 * K);) {
-        if (j < (unsigned)(K * K)) wk_sample_ntt(cst, my_rho, j % K, j / K, my_A + j * 256, sq[wv]);
-        else wk_prf(cst, my_sigma, j - K * K, (unsigned)ETA1, (unsigned)prf_rate, my_prf + (j - K * K) * PS);
-    }
+    small_jobs<K, ETA1, ETA1>(sy, cst, my_rho, /*transpose=*/false, my_A, my_sigma, my_prf, 2 * K, (unsigned)prf_rate, sq[wv]);
     block_barrier();
     if (wv == 0) {
         keygen2_body<K, ETA1, KEM_DK>(xl.xch, 0, 1, my_A, my_prf, my_rho, my_ek, my_dk);

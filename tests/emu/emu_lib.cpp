@@ -14,6 +14,7 @@ static int g_fips = 0;
 static size_t g_wide = 0;       // items up to which the one-sponge-per-wave hash kernels run (64 host threads shuffle slowly: off unless a test asks)
 static size_t g_small = 0;      // items up to which the one-workgroup-per-item kernels run (512 host threads per item: off unless a test asks)
 static size_t g_small_lat = 128; // ... of which calls up to this size use eight waves per item, larger ones four
+static size_t g_small_wide = 0;  // ... and Decaps calls up to this size twelve (768 host threads per item: off unless a test asks)
 static int g_resume_cap = 64;   // resume records per chunk; a small value exercises the overflow into the restart list
 
 static void* xalloc(size_t bytes) { return aligned_alloc(64, (bytes + 127) / 64 * 64); }
@@ -27,6 +28,7 @@ static Workspace make_ws(size_t n) {
     ws.wide_max = g_wide;
     ws.small_max = g_small;
     ws.small_lat_max = g_small_lat;
+    ws.small_wide_max = g_small_wide;
     ws.A = (uint16_t*)xalloc(ws.cap * 16 * 512);
     ws.prf = (uint8_t*)xalloc(ws.cap * 9 * 192);
     ws.leftover = (uint32_t*)xalloc((ws.cap * 16 + 2) * 4);
@@ -79,6 +81,7 @@ void emu_conformance(int fips) { g_fips = fips != 0; }
 void emu_wide_hash(size_t items) { g_wide = items; }
 void emu_small(size_t items) { g_small = items; }
 void emu_small_latency(size_t items) { g_small_lat = items; }
+void emu_small_wide(size_t items) { g_small_wide = items; }
 void emu_resume_cap(int cap) { g_resume_cap = cap < 0 ? 0 : cap; }
 int emu_keygen(int set, size_t n, const uint8_t* d, const uint8_t* z, uint8_t* ek, uint8_t* dk) {
     Workspace ws = make_ws(n);

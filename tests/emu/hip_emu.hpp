@@ -7,6 +7,7 @@
 // against the oracle in the CPU test tier; it is never part of, nor a fallback for, libmlkem_amd.so.
 #pragma once
 #include <pthread.h>
+#include <sched.h>
 #include <stdint.h>
 #include <string.h>
 

@@ -537,17 +537,19 @@ def test_emu_one_sponge_per_wave_hash_kernels(emu, oracle, pset, fips):
         oracle.set_conformance(False)
 
 
-@pytest.mark.parametrize("pset,fips,waves", ((512, 0, 4), (768, 0, 8), (1024, 1, 8)))
+@pytest.mark.parametrize("pset,fips,waves", ((512, 0, 4), (768, 0, 8), (1024, 1, 12)))
 def test_emu_one_workgroup_per_item_kernels(emu, oracle, pset, fips, waves):
     """mlkem_small.hpp (calls of at most `small_max` items): KeyGen, Encaps and Decaps each as ONE launch, a workgroup of eight
-    (latency form) or four (dense form) waves per item -- wave-level SampleNTT (ballot + prefix-count compaction) dealt out by a
-    counter in LDS, PRF, H / G / J and the K-PKE bodies behind workgroup barriers.  An untouched and a tampered ciphertext (two items for 768, one for the others), then a corrupted stored
+    (latency form; twelve for Decaps of 1024) or four (dense form) waves per item -- wave-level SampleNTT (ballot + prefix-count
+    compaction) and the PRF rows dealt out as jobs by a counter in LDS, H / G / J and the K-PKE bodies, handed over between the waves
+    by flag counters in LDS (flag_signal / flag_wait).  An untouched and a tampered ciphertext (two items for 768, one for the others), then a corrupted stored
     H(ek) with the untouched ciphertext; bit for bit against the oracle (reference mode for 512 / 768, FIPS 203 mode -- PRF and J on SHAKE256 -- for 1024)."""
     n = 1
     ekl, dkl, cl = SIZES[pset]
     emu.emu_conformance(fips)
     emu.emu_small(C.c_size_t(16))
-    emu.emu_small_latency(C.c_size_t(16 if waves == 8 else 0))
+    emu.emu_small_latency(C.c_size_t(16 if waves >= 8 else 0))
+    emu.emu_small_wide(C.c_size_t(16 if waves == 12 else 0))     # Decaps of k >= 3 with twelve waves
     try:
         d, z, m = seeds("sm-d", n, pset), seeds("sm-z", n, pset), seeds("sm-m", n, pset)
         oracle.set_conformance(bool(fips))
@@ -577,6 +579,7 @@ def test_emu_one_workgroup_per_item_kernels(emu, oracle, pset, fips, waves):
     finally:
         emu.emu_small(C.c_size_t(0))
         emu.emu_small_latency(C.c_size_t(128))
+        emu.emu_small_wide(C.c_size_t(0))
         emu.emu_conformance(0)
         oracle.set_conformance(False)
 

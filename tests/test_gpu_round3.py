@@ -344,10 +344,11 @@ def test_every_ciphertext_byte_takes_part_in_the_compare(pkg, torch, oracle, pse
 # ---- calls of one chunk: matrix sampling on the context's side stream ------------------------------------------------------
 @pytest.mark.parametrize("env", ({}, {"MLKEM_SMALL_ITEMS": "0"}, {"MLKEM_SMALL_ITEMS": "0", "MLKEM_SIDE_STREAM": "0"},
                                  {"MLKEM_SMALL_ITEMS": "0", "MLKEM_WIDE_HASH_ITEMS": "0"}, {"MLKEM_SMALL_ITEMS": "0", "MLKEM_WIDE_HASH_ITEMS": "100000"},
-                                 {"MLKEM_SMALL_ITEMS": "100000", "MLKEM_SMALL_LATENCY_ITEMS": "100000"},
-                                 {"MLKEM_SMALL_ITEMS": "100000", "MLKEM_SMALL_LATENCY_ITEMS": "0"}),
+                                 {"MLKEM_SMALL_ITEMS": "100000", "MLKEM_SMALL_LATENCY_ITEMS": "100000", "MLKEM_SMALL_WIDE_ITEMS": "0"},
+                                 {"MLKEM_SMALL_ITEMS": "100000", "MLKEM_SMALL_LATENCY_ITEMS": "100000", "MLKEM_SMALL_WIDE_ITEMS": "100000"},
+                                 {"MLKEM_SMALL_ITEMS": "100000", "MLKEM_SMALL_LATENCY_ITEMS": "0", "MLKEM_SMALL_WIDE_ITEMS": "0"}),
                          ids=("default", "side-stream", "one-stream", "lane-sliced-hashes", "one-sponge-per-wave-hashes", "one-workgroup-per-item-8-waves",
-                              "one-workgroup-per-item-4-waves"))
+                              "one-workgroup-per-item-12-wave-decaps", "one-workgroup-per-item-4-waves"))
 @pytest.mark.parametrize("pset,n", ((768, 1000), (512, 3), (1024, 130)))
 def test_single_chunk_calls_keep_their_results_with_and_without_the_side_stream(pkg, torch, oracle, env, monkeypatch, pset, n):
     """A call that fits one chunk samples A-hat on the context's side stream while H(ek) / G (encaps) or Decrypt and the
@@ -380,9 +381,9 @@ def test_single_chunk_calls_keep_their_results_with_and_without_the_side_stream(
     e.close()
 
 
-@pytest.mark.parametrize("n", (1, 2, 256, 257, 320, 321, 512, 895, 896, 897, 2047, 2048, 2049))
+@pytest.mark.parametrize("n", (1, 2, 128, 129, 256, 257, 320, 321, 512, 895, 896, 897, 2047, 2048, 2049))
 def test_default_path_switches_at_their_boundaries(pkg, torch, oracle, n):
-    """The sizes either side of Workspace::small_lat_max (320: one workgroup of eight | of four waves per item; 256 | 257: the end
+    """The sizes either side of Workspace::small_wide_max (128: Decaps with twelve | eight waves per item), Workspace::small_lat_max (320: one workgroup of eight | of four waves per item; 256 | 257: the end
     of the eight-wave form's first round), Workspace::small_max (896: one workgroup per item | batch kernels) and Workspace::wide_max
     (2048: one sponge per wave + direct sampler | lane-sliced hashes + three-block sampler), default environment, one chunk
     (chunk_items 4096): ML-KEM-768 keygen -> encaps -> decaps with tampered ciphertexts and one corrupted stored hash."""
