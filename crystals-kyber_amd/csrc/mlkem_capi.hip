@@ -708,14 +708,16 @@ size_t default_stream_chunk() {
 }
 
 // runs on the calling thread; the engine's device must be current
+// pre_locked: the caller already holds e.mu (kem_stream_current picks a free engine by try_lock)
 template <class Launch>
-int stream_op(StreamEngine& e, size_t n, size_t chunk, const std::vector<Span>& spans, Launch launch) {
+int stream_op(StreamEngine& e, size_t n, size_t chunk, const std::vector<Span>& spans, Launch launch, bool pre_locked = false) {
     if (n == 0) return MLKEM_OK;
     if (chunk == 0) chunk = default_stream_chunk();
     if (chunk > n) chunk = n;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return MLKEM_ERR_NO_DEVICE;
-    std::lock_guard<std::mutex> lock(e.mu);
+    std::unique_lock<std::mutex> lock(e.mu, std::defer_lock);
+    if (!pre_locked) lock.lock();
     const size_t nchunks = (n + chunk - 1) / chunk;
     const int nsets = nchunks < (size_t)NSETS ? (int)nchunks : NSETS;
     std::vector<char> staged(spans.size());
@@ -836,16 +838,41 @@ int stream_op(StreamEngine& e, size_t n, size_t chunk, const std::vector<Span>& 
 // reference; a call that had already looked its entry up keeps the object alive, finds it empty, rebuilds what it needs in
 // the orphaned entry, and the destructor wipes and frees that when the call returns.  Release is therefore safe to call
 // from any thread at any time.
+size_t host_lanes_max() {   // env MLKEM_HOST_LANES (0: one engine per device, calls of other threads queue)
+    static const size_t v = [] {
+        const char* e = getenv("MLKEM_HOST_LANES");
+        long long x = e ? atoll(e) : 7;
+        return (size_t)(x < 0 ? 0 : (x > 63 ? 63 : x));
+    }();
+    return v;
+}
 struct HostState {
     std::mutex mu;              // serialises the host-pointer primitives of one device
     int device = 0;
     mlkem_ctx* ctx = nullptr;   // chunk capacity 1: the primitives use no scratch
     StreamEngine eng;
-    void wipe() {               // zero + free everything cached; the entry stays usable (contents are rebuilt on demand)
+    // Further engines ("lanes") for host threads that call while `eng` is busy: every lane has its own streams, staging buffers
+    // and context, so that one-item calls of a multi-threaded host (the ml_kem.h shim under a server) run side by side on the
+    // GPU instead of queueing on one mutex.  Opened on demand, at most host_lanes_max(); the objects live as long as the entry.
+    std::mutex lanes_mu;
+    std::vector<std::unique_ptr<StreamEngine>> lanes;
+    void release_engines() {
         {
             std::lock_guard<std::mutex> l2(eng.mu);
             engine_release(eng);
         }
+        std::vector<StreamEngine*> all;
+        {
+            std::lock_guard<std::mutex> lg(lanes_mu);
+            for (auto& l : lanes) all.push_back(l.get());
+        }
+        for (StreamEngine* l : all) {   // waits for a call in flight on that lane
+            std::lock_guard<std::mutex> l2(l->mu);
+            engine_release(*l);
+        }
+    }
+    void wipe() {               // zero + free everything cached; the entry stays usable (contents are rebuilt on demand)
+        release_engines();
         std::lock_guard<std::mutex> l3(mu);
         if (ctx) mlkem_ctx_destroy(ctx);
         ctx = nullptr;
@@ -901,7 +928,7 @@ int guarded(Fn fn) {
 }
 
 // the three KEM operations as (spans, launch) pairs for stream_op
-int kem_stream(StreamEngine& e, int op, int set, size_t n, const void* a, const void* b, void* x, void* y, size_t chunk) {
+int kem_stream(StreamEngine& e, int op, int set, size_t n, const void* a, const void* b, void* x, void* y, size_t chunk, bool pre_locked = false) {
     ParamSet p;
     if (!param_set(set, p)) return MLKEM_ERR_PARAM_SET;
     if (n && (!a || !b || !x || !y)) return MLKEM_ERR_ARG;
@@ -909,26 +936,42 @@ int kem_stream(StreamEngine& e, int op, int set, size_t n, const void* a, const 
         std::vector<Span> sp = {{a, nullptr, 32}, {b, nullptr, 32}, {nullptr, x, p.ek_len}, {nullptr, y, p.dk_len}};
         return stream_op(e, n, chunk, sp, [&](mlkem_ctx* ctx, size_t cnt, const std::vector<void*>& v, hipStream_t st) {
             return mlkem_keygen_dev(ctx, set, cnt, (const uint8_t*)v[0], (const uint8_t*)v[1], (uint8_t*)v[2], (uint8_t*)v[3], st);
-        });
+        }, pre_locked);
     }
     if (op == 1) {   // encaps: ek, m -> c, K
         std::vector<Span> sp = {{a, nullptr, p.ek_len}, {b, nullptr, 32}, {nullptr, x, p.c_len}, {nullptr, y, 32}};
         return stream_op(e, n, chunk, sp, [&](mlkem_ctx* ctx, size_t cnt, const std::vector<void*>& v, hipStream_t st) {
             return mlkem_encaps_dev(ctx, set, cnt, (const uint8_t*)v[0], (const uint8_t*)v[1], (uint8_t*)v[2], (uint8_t*)v[3], st);
-        });
+        }, pre_locked);
     }
     // decaps: dk, c -> K, status
     std::vector<Span> sp = {{a, nullptr, p.dk_len}, {b, nullptr, p.c_len}, {nullptr, x, 32}, {nullptr, y, 4}};
     return stream_op(e, n, chunk, sp, [&](mlkem_ctx* ctx, size_t cnt, const std::vector<void*>& v, hipStream_t st) {
         return mlkem_decaps_dev(ctx, set, cnt, (const uint8_t*)v[0], (const uint8_t*)v[1], (uint8_t*)v[2], (int32_t*)v[3], st);
-    });
+    }, pre_locked);
 }
 
 int kem_stream_current(int op, int set, size_t n, const void* a, const void* b, void* x, void* y, size_t chunk) {
     return guarded([&]() -> int {
         HostRef hs = host_state_current();
         if (!hs) return MLKEM_ERR_NO_DEVICE;
-        return kem_stream(hs->eng, op, set, n, a, b, x, y, chunk);
+        // the first free engine: the device's own, else a lane (opened on demand); all busy: queue on the device's own
+        StreamEngine* e = &hs->eng;
+        std::unique_lock<std::mutex> held(e->mu, std::try_to_lock);
+        if (!held.owns_lock()) {
+            std::lock_guard<std::mutex> lg(hs->lanes_mu);
+            for (auto& l : hs->lanes) {
+                held = std::unique_lock<std::mutex>(l->mu, std::try_to_lock);
+                if (held.owns_lock()) { e = l.get(); break; }
+            }
+            if (!held.owns_lock() && hs->lanes.size() < host_lanes_max()) {
+                hs->lanes.emplace_back(new StreamEngine());
+                e = hs->lanes.back().get();
+                held = std::unique_lock<std::mutex>(e->mu);
+            }
+        }
+        if (!held.owns_lock()) held = std::unique_lock<std::mutex>(e->mu);   // e is still the device's own engine
+        return kem_stream(*e, op, set, n, a, b, x, y, chunk, /*pre_locked=*/true);
     });
 }
 
@@ -974,10 +1017,7 @@ int mlkem_host_unregister(void* p) {
 }
 
 void mlkem_stream_release(void) {
-    for (HostRef& hs : host_state_snapshot(false)) {
-        std::lock_guard<std::mutex> l2(hs->eng.mu);
-        engine_release(hs->eng);
-    }
+    for (HostRef& hs : host_state_snapshot(false)) hs->release_engines();
 }
 // wipes and frees everything the host-pointer entry points cached, on every device they were used on; safe against calls
 // in flight on other threads (see HostState)

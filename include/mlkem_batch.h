@@ -224,7 +224,11 @@ MLKEM_API int mlkem_decompress(int d, size_t n, const uint16_t* y, uint16_t* x);
  * work on different devices share nothing.  mlkem_host_release() zeroes and frees all of it (contexts, streams, pinned and
  * device staging) on every device; mlkem_stream_release() only the streaming engines.  Both may be called from any thread
  * at any time: the cached state is reference-counted, a release waits for calls in flight on the same device's locks, and
- * a call that overlaps a release simply rebuilds (and afterwards frees) what it needs. */
+ * a call that overlaps a release simply rebuilds (and afterwards frees) what it needs.
+ * Threads that call the host-pointer KEM entry points on the SAME device at the same time each get a streaming engine of
+ * their own (streams, staging buffers, context; up to 1 + MLKEM_HOST_LANES = 8 per device, further callers queue), so that
+ * the one-item calls of a multi-threaded host run side by side on the GPU; the host-pointer primitives (mlkem_ntt, ...)
+ * share one context per device and queue. */
 MLKEM_API void mlkem_host_release(void);
 
 /* ---- layout converters and streaming front-end --------------------------------------------------

@@ -8,6 +8,7 @@ import socket
 import subprocess
 import sys
 import threading
+import time
 
 import numpy as np
 import pytest
@@ -238,6 +239,51 @@ def test_host_release_races_with_calls_in_flight(pkg, oracle):
             lib.mlkem_stream_release()
 
     ts = [threading.Thread(target=kem_caller), threading.Thread(target=prim_caller)]
+    rel = threading.Thread(target=releaser)
+    rel.start()
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    stop.set()
+    rel.join()
+    assert not bad, bad[:5]
+    lib.mlkem_host_release()
+
+
+def test_concurrent_host_threads_get_engines_of_their_own(pkg, oracle):
+    """Six host threads make one- and three-item host-pointer calls at once (what a multi-threaded host of the ml_kem.h shim does):
+    the library hands each concurrent caller an engine of its own -- streams, staging buffers, context (HostState::lanes,
+    mlkem_capi.hip) -- instead of queueing them on one mutex.  Every thread's keys, ciphertexts and shared secrets equal the
+    oracle's, with a tampered ciphertext per round; a seventh thread releases the cached state (lanes included) meanwhile."""
+    lib = pkg.load_library()
+    bad = []
+    stop = threading.Event()
+
+    def caller(tid):
+        n = 1 if tid % 2 == 0 else 3
+        d, z, m = seeds("lane-d%d" % tid, n, 5), seeds("lane-z%d" % tid, n, 5), seeds("lane-m%d" % tid, n, 5)
+        ek_o, dk_o = oracle.keygen(768, d, z)
+        c_o, K_o = oracle.encaps(768, ek_o, m)
+        cb = c_o.copy()
+        cb[n - 1, 3 + tid] ^= 0x40
+        Kd_o, st_o = oracle.decaps(768, dk_o, cb)
+        for rnd in range(40):
+            ek, dk = np.zeros((n, 1184), np.uint8), np.zeros((n, 2400), np.uint8)
+            c, K, Kd, st = np.zeros((n, 1088), np.uint8), np.zeros((n, 32), np.uint8), np.zeros((n, 32), np.uint8), np.ones(n, np.int32)
+            rc = lib.mlkem_keygen(768, n, d.ctypes.data, z.ctypes.data, ek.ctypes.data, dk.ctypes.data)
+            rc |= lib.mlkem_encaps(768, n, ek.ctypes.data, m.ctypes.data, c.ctypes.data, K.ctypes.data)
+            rc |= lib.mlkem_decaps(768, n, dk.ctypes.data, cb.ctypes.data, Kd.ctypes.data, st.ctypes.data)
+            if rc or not ((ek == ek_o).all() and (dk == dk_o).all() and (c == c_o).all() and (K == K_o).all()
+                          and (Kd == Kd_o).all() and (st == st_o).all()):
+                bad.append((tid, rnd, rc))
+
+    def releaser():
+        while not stop.is_set():
+            lib.mlkem_stream_release()
+            time.sleep(0.002)
+
+    ts = [threading.Thread(target=caller, args=(t,)) for t in range(6)]
     rel = threading.Thread(target=releaser)
     rel.start()
     for t in ts:
