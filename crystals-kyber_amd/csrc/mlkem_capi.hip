@@ -955,7 +955,7 @@ int kem_stream_current(int op, int set, size_t n, const void* a, const void* b, 
     return guarded([&]() -> int {
         HostRef hs = host_state_current();
         if (!hs) return MLKEM_ERR_NO_DEVICE;
-        // the first free engine: the device's own, else a lane (opened on demand); all busy: queue on the device's own
+        // the first free engine: the device's own, else a lane (opened on demand); all busy: queue on one of them, spread by thread
         StreamEngine* e = &hs->eng;
         std::unique_lock<std::mutex> held(e->mu, std::try_to_lock);
         if (!held.owns_lock()) {
@@ -969,8 +969,12 @@ int kem_stream_current(int op, int set, size_t n, const void* a, const void* b, 
                 e = hs->lanes.back().get();
                 held = std::unique_lock<std::mutex>(e->mu);
             }
+            if (!held.owns_lock()) {
+                const size_t pick = std::hash<std::thread::id>()(std::this_thread::get_id()) % (hs->lanes.size() + 1);
+                if (pick) e = hs->lanes[pick - 1].get();
+            }
         }
-        if (!held.owns_lock()) held = std::unique_lock<std::mutex>(e->mu);   // e is still the device's own engine
+        if (!held.owns_lock()) held = std::unique_lock<std::mutex>(e->mu);
         return kem_stream(*e, op, set, n, a, b, x, y, chunk, /*pre_locked=*/true);
     });
 }
