@@ -216,6 +216,7 @@ def main():
                 L.append("* streaming %d items, %s buffers: %.3g pairs/s at chunk %s (`profiles/%s_stream_bench.json`)" % (sb["items"], kind, v, k.rsplit("_", 1)[1], TAG))
         L.append("")
     for name, title in (("soak.txt", "Sustained run (`tools/soak.py`)"),
+                        ("soak_small.txt", "Sustained run of the small-call kernels, random sizes and parameter sets on two streams (`tools/soak_small.py`)"),
                         ("small_kernel_stats.txt", "Small-call kernels under rocprofv3 (`tools/small_profile.sh`)"),
                         ("small_stamps.txt", "Where a one-item Encaps spends its time, stage by stage (`tools/small_stamps.hip`)"),
                         ("keygen_latency.txt", "Device-resident call latency per parameter set and operation (`tools/keygen_latency.py`)"),

@@ -36,6 +36,7 @@ cp $D/keccak_wave_ubench.txt profiles/${T}_keccak_wave_ubench.txt
 cp $D/energy.txt profiles/${T}_energy.txt
 cp $D/small_stamps.txt profiles/${T}_small_stamps.txt
 cp $D/host_threads.txt profiles/${T}_host_threads.txt
+cp $D/soak_small.txt profiles/${T}_soak_small.txt
 cp $D/host_path_breakdown.txt profiles/${T}_host_path_breakdown.txt
 cp $D/small_kernel_stats.txt profiles/${T}_small_kernel_stats.txt
 cp $D/gpu_tier.log profiles/${T}_gpu_tier.log
