@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string.h>
+#include <algorithm>
 #include <condition_variable>
 #include <functional>
 #include <map>
@@ -846,6 +847,37 @@ size_t host_lanes_max() {   // env MLKEM_HOST_LANES (0: one engine per device, c
     }();
     return v;
 }
+// Calls of a few items (the ml_kem.h shim makes calls of one) that arrive while other such calls of the same operation and
+// parameter set are in flight are COMBINED: the first caller that finds fewer than host_combine_leaders() batches in flight becomes a
+// leader, takes everything that has queued up, runs it as ONE call (one launch + one synchronise for the whole batch) and hands the
+// results back; the others sleep until their request is done.  A lone caller is its own leader at once: no waiting is added.
+// One launch + synchronise costs the host ~50 us whatever it carries, so a host with many threads is limited by calls per
+// second, not by the GPU (profiles/r04_host_threads.txt).  MLKEM_HOST_COMBINE=0 turns it off.
+struct CombineReq {
+    const uint8_t *a, *b;
+    uint8_t *x, *y;
+    size_t n;
+    int rc = MLKEM_OK;
+    bool taken = false;      // a leader has it in its batch: the owner must wait for `done`, not lead
+    bool done = false, combined = false;
+};
+struct Combiner {
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<CombineReq*> waiting;
+    int leaders = 0;
+};
+constexpr size_t COMBINE_MAX_ITEMS = 4;    // per request
+constexpr size_t COMBINE_MAX_BATCH = 256;  // items per combined call: one eight-wave workgroup per CU
+int host_combine_leaders() {   // batches in flight per operation and parameter set; env MLKEM_HOST_COMBINE (0: no combining)
+    static const int v = [] {
+        const char* e = getenv("MLKEM_HOST_COMBINE");
+        const int x = e ? atoi(e) : 2;   // 2: best from 16 host threads up; 3-4 is ~10 % better at four (profiles/r04_host_threads.txt)
+        return x < 0 ? 0 : (x > 16 ? 16 : x);
+    }();
+    return v;
+}
+bool host_combine_enabled() { return host_combine_leaders() > 0; }
 struct HostState {
     std::mutex mu;              // serialises the host-pointer primitives of one device
     int device = 0;
@@ -856,6 +888,7 @@ struct HostState {
     // GPU instead of queueing on one mutex.  Opened on demand, at most host_lanes_max(); the objects live as long as the entry.
     std::mutex lanes_mu;
     std::vector<std::unique_ptr<StreamEngine>> lanes;
+    Combiner comb[9];           // [operation][parameter set]
     void release_engines() {
         {
             std::lock_guard<std::mutex> l2(eng.mu);
@@ -951,10 +984,93 @@ int kem_stream(StreamEngine& e, int op, int set, size_t n, const void* a, const 
     }, pre_locked);
 }
 
+int kem_on_free_engine(HostState* hs, int op, int set, size_t n, const void* a, const void* b, void* x, void* y, size_t chunk);
+
+// see Combiner
+int kem_combined(HostState* hs, int op, int set, size_t n, const void* a, const void* b, void* x, void* y) {
+    ParamSet p;
+    if (!param_set(set, p)) return MLKEM_ERR_PARAM_SET;
+    if (!a || !b || !x || !y) return MLKEM_ERR_ARG;
+    const size_t sz[3][4] = {{32, 32, p.ek_len, p.dk_len}, {p.ek_len, 32, p.c_len, 32}, {p.dk_len, p.c_len, 32, 4}};
+    const size_t* w = sz[op];
+    Combiner& cb = hs->comb[op * 3 + (set == 512 ? 0 : set == 768 ? 1 : 2)];
+    CombineReq me{static_cast<const uint8_t*>(a), static_cast<const uint8_t*>(b), static_cast<uint8_t*>(x), static_cast<uint8_t*>(y), n};
+    std::unique_lock<std::mutex> lk(cb.mu);
+    cb.waiting.push_back(&me);
+    for (;;) {
+        if (me.done) {
+            if (me.combined) t_last_staged = 15;   // every operand went through the leader's batch buffers
+            return me.rc;
+        }
+        if (!me.taken && cb.leaders < host_combine_leaders()) break;
+        cb.cv.wait(lk);
+    }
+    // leader: my own request (still queued, not taken) and whatever else fits
+    std::vector<CombineReq*> batch, rest;
+    size_t total = me.n;
+    try {
+        batch.reserve(cb.waiting.size());
+        rest.reserve(cb.waiting.size());
+    } catch (...) {   // nothing has been taken yet: withdraw my request
+        cb.waiting.erase(std::find(cb.waiting.begin(), cb.waiting.end(), &me));
+        return MLKEM_ERR_ALLOC;
+    }
+    batch.push_back(&me);
+    for (CombineReq* r : cb.waiting) {
+        if (r == &me) continue;
+        if (total + r->n <= COMBINE_MAX_BATCH) { batch.push_back(r); total += r->n; r->taken = true; }
+        else rest.push_back(r);
+    }
+    cb.waiting.swap(rest);
+    cb.leaders++;
+    lk.unlock();
+    int rc = MLKEM_OK;
+    try {
+        if (batch.size() == 1) {
+            rc = kem_on_free_engine(hs, op, set, me.n, me.a, me.b, me.x, me.y, 0);
+        } else {
+            std::vector<uint8_t> A(total * w[0]), B(total * w[1]), X(total * w[2]), Y(total * w[3]);
+            size_t off = 0;
+            for (CombineReq* r : batch) {
+                memcpy(A.data() + off * w[0], r->a, r->n * w[0]);
+                memcpy(B.data() + off * w[1], r->b, r->n * w[1]);
+                off += r->n;
+            }
+            rc = kem_on_free_engine(hs, op, set, total, A.data(), B.data(), X.data(), Y.data(), 0);
+            off = 0;
+            for (CombineReq* r : batch) {
+                if (rc == MLKEM_OK) {
+                    memcpy(r->x, X.data() + off * w[2], r->n * w[2]);
+                    memcpy(r->y, Y.data() + off * w[3], r->n * w[3]);
+                }
+                off += r->n;
+            }
+            explicit_bzero(A.data(), A.size()); explicit_bzero(B.data(), B.size());   // seeds, keys, shared secrets
+            explicit_bzero(X.data(), X.size()); explicit_bzero(Y.data(), Y.size());
+        }
+    } catch (...) {   // allocation or thread-resource failure: every request of the batch gets the error
+        rc = MLKEM_ERR_ALLOC;
+    }
+    lk.lock();
+    const bool combined = batch.size() > 1;
+    for (CombineReq* r : batch) { r->rc = rc; r->combined = combined; r->done = true; }   // a waiter may return (its request gone) from here on
+    cb.leaders--;
+    cb.cv.notify_all();
+    if (combined) t_last_staged = 15;
+    return rc;
+}
+
 int kem_stream_current(int op, int set, size_t n, const void* a, const void* b, void* x, void* y, size_t chunk) {
     return guarded([&]() -> int {
         HostRef hs = host_state_current();
         if (!hs) return MLKEM_ERR_NO_DEVICE;
+        if (n && n <= COMBINE_MAX_ITEMS && chunk == 0 && host_combine_enabled()) return kem_combined(hs.get(), op, set, n, a, b, x, y);
+        return kem_on_free_engine(hs.get(), op, set, n, a, b, x, y, chunk);
+    });
+}
+
+int kem_on_free_engine(HostState* hs, int op, int set, size_t n, const void* a, const void* b, void* x, void* y, size_t chunk) {
+    {
         // the first free engine: the device's own, else a lane (opened on demand); all busy: queue on one of them, spread by thread
         StreamEngine* e = &hs->eng;
         std::unique_lock<std::mutex> held(e->mu, std::try_to_lock);
@@ -976,7 +1092,7 @@ int kem_stream_current(int op, int set, size_t n, const void* a, const void* b, 
         }
         if (!held.owns_lock()) held = std::unique_lock<std::mutex>(e->mu);
         return kem_stream(*e, op, set, n, a, b, x, y, chunk, /*pre_locked=*/true);
-    });
+    }
 }
 
 }   // namespace

@@ -228,7 +228,10 @@ MLKEM_API int mlkem_decompress(int d, size_t n, const uint16_t* y, uint16_t* x);
  * Threads that call the host-pointer KEM entry points on the SAME device at the same time each get a streaming engine of
  * their own (streams, staging buffers, context; up to 1 + MLKEM_HOST_LANES = 8 per device, further callers queue), so that
  * the one-item calls of a multi-threaded host run side by side on the GPU; the host-pointer primitives (mlkem_ntt, ...)
- * share one context per device and queue. */
+ * share one context per device and queue.  KEM calls of at most 4 items (the ml_kem.h shim makes calls of one) that arrive
+ * while others of the same operation and parameter set are in flight are COMBINED into one launch by whichever caller finds
+ * fewer than MLKEM_HOST_COMBINE (default 2; 0: never) batches in flight; a lone caller never waits.  Results and error codes
+ * are those of the separate calls. */
 MLKEM_API void mlkem_host_release(void);
 
 /* ---- layout converters and streaming front-end --------------------------------------------------

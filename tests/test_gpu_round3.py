@@ -251,49 +251,54 @@ def test_host_release_races_with_calls_in_flight(pkg, oracle):
     lib.mlkem_host_release()
 
 
-def test_concurrent_host_threads_get_engines_of_their_own(pkg, oracle):
-    """Six host threads make one- and three-item host-pointer calls at once (what a multi-threaded host of the ml_kem.h shim does):
-    the library hands each concurrent caller an engine of its own -- streams, staging buffers, context (HostState::lanes,
-    mlkem_capi.hip) -- instead of queueing them on one mutex.  Every thread's keys, ciphertexts and shared secrets equal the
-    oracle's, with a tampered ciphertext per round; a seventh thread releases the cached state (lanes included) meanwhile."""
-    lib = pkg.load_library()
-    bad = []
-    stop = threading.Event()
-
-    def caller(tid):
-        n = 1 if tid % 2 == 0 else 3
-        d, z, m = seeds("lane-d%d" % tid, n, 5), seeds("lane-z%d" % tid, n, 5), seeds("lane-m%d" % tid, n, 5)
-        ek_o, dk_o = oracle.keygen(768, d, z)
-        c_o, K_o = oracle.encaps(768, ek_o, m)
-        cb = c_o.copy()
-        cb[n - 1, 3 + tid] ^= 0x40
-        Kd_o, st_o = oracle.decaps(768, dk_o, cb)
-        for rnd in range(40):
-            ek, dk = np.zeros((n, 1184), np.uint8), np.zeros((n, 2400), np.uint8)
-            c, K, Kd, st = np.zeros((n, 1088), np.uint8), np.zeros((n, 32), np.uint8), np.zeros((n, 32), np.uint8), np.ones(n, np.int32)
-            rc = lib.mlkem_keygen(768, n, d.ctypes.data, z.ctypes.data, ek.ctypes.data, dk.ctypes.data)
-            rc |= lib.mlkem_encaps(768, n, ek.ctypes.data, m.ctypes.data, c.ctypes.data, K.ctypes.data)
-            rc |= lib.mlkem_decaps(768, n, dk.ctypes.data, cb.ctypes.data, Kd.ctypes.data, st.ctypes.data)
-            if rc or not ((ek == ek_o).all() and (dk == dk_o).all() and (c == c_o).all() and (K == K_o).all()
-                          and (Kd == Kd_o).all() and (st == st_o).all()):
-                bad.append((tid, rnd, rc))
-
-    def releaser():
-        while not stop.is_set():
-            lib.mlkem_stream_release()
-            time.sleep(0.002)
-
-    ts = [threading.Thread(target=caller, args=(t,)) for t in range(6)]
-    rel = threading.Thread(target=releaser)
-    rel.start()
-    for t in ts:
-        t.start()
-    for t in ts:
-        t.join()
-    stop.set()
-    rel.join()
-    assert not bad, bad[:5]
-    lib.mlkem_host_release()
+@pytest.mark.parametrize("combine", ("2", "0"))
+def test_concurrent_host_threads_are_combined_or_get_engines_of_their_own(combine):
+    """Twelve host threads make one- and three-item host-pointer calls at once (what a multi-threaded host of the ml_kem.h shim
+    does).  Default: calls of the same operation that arrive while others are in flight are combined into one launch by a leader
+    (Combiner, mlkem_capi.hip); MLKEM_HOST_COMBINE=0: every concurrent caller gets an engine of its own (HostState::lanes) or
+    queues on one.  Either way every thread's keys, ciphertexts and shared secrets equal the oracle's, with a tampered
+    ciphertext per round, while a further thread keeps releasing the cached engines."""
+    code = r'''
+import sys, threading, time, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r + "/tests")
+import __graft_entry__ as ge
+from conftest import seeds
+from oracle.loader import Oracle
+pkg = ge.load_package(); lib = pkg.load_library(); oracle = Oracle()
+bad, stop = [], threading.Event()
+def caller(tid):
+    n = 1 if tid %% 2 == 0 else 3
+    d, z, m = seeds("lane-d%%d" %% tid, n, 5), seeds("lane-z%%d" %% tid, n, 5), seeds("lane-m%%d" %% tid, n, 5)
+    ek_o, dk_o = oracle.keygen(768, d, z)
+    c_o, K_o = oracle.encaps(768, ek_o, m)
+    cb = c_o.copy()
+    cb[n - 1, 3 + tid] ^= 0x40
+    Kd_o, st_o = oracle.decaps(768, dk_o, cb)
+    for rnd in range(30):
+        ek, dk = np.zeros((n, 1184), np.uint8), np.zeros((n, 2400), np.uint8)
+        c, K, Kd, st = np.zeros((n, 1088), np.uint8), np.zeros((n, 32), np.uint8), np.zeros((n, 32), np.uint8), np.ones(n, np.int32)
+        rc = lib.mlkem_keygen(768, n, d.ctypes.data, z.ctypes.data, ek.ctypes.data, dk.ctypes.data)
+        rc |= lib.mlkem_encaps(768, n, ek.ctypes.data, m.ctypes.data, c.ctypes.data, K.ctypes.data)
+        rc |= lib.mlkem_decaps(768, n, dk.ctypes.data, cb.ctypes.data, Kd.ctypes.data, st.ctypes.data)
+        if rc or not ((ek == ek_o).all() and (dk == dk_o).all() and (c == c_o).all() and (K == K_o).all()
+                      and (Kd == Kd_o).all() and (st == st_o).all()):
+            bad.append((tid, rnd, rc))
+def releaser():
+    while not stop.is_set():
+        lib.mlkem_stream_release()
+        time.sleep(0.002)
+ts = [threading.Thread(target=caller, args=(t,)) for t in range(12)]
+rel = threading.Thread(target=releaser)
+rel.start()
+[t.start() for t in ts]
+[t.join() for t in ts]
+stop.set(); rel.join()
+lib.mlkem_host_release()
+print("bad", bad[:5])
+sys.exit(1 if bad else 0)
+''' % (ROOT, ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, MLKEM_HOST_COMBINE=combine), timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
 
 
 # ---- bench.py: the N > 1 line carries what configs[4] is defined by --------------------------------------------------------
