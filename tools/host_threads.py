@@ -47,6 +47,6 @@ for T in (1, 2, 4, 8, 16):
         t.join()
     wall = max(v[0] for v in out.values())
     bad = sum(v[1] for v in out.values())
-    print("MLKEM_HOST_LANES=%s threads=%2d: %8.0f pairs/s  (%.1f us per pair and thread, errors %d)" % (
-        os.environ.get("MLKEM_HOST_LANES", "default"), T, T * R / wall, wall / R * 1e6, bad))
+    print("MLKEM_HOST_LANES=%s MLKEM_HOST_COMBINE=%s threads=%2d: %8.0f pairs/s  (%.1f us per pair and thread, errors %d)" % (
+        os.environ.get("MLKEM_HOST_LANES", "default"), os.environ.get("MLKEM_HOST_COMBINE", "default"), T, T * R / wall, wall / R * 1e6, bad))
 lib.mlkem_host_release()

@@ -46,7 +46,7 @@ timeout -k 10 100 python3 tools/keygen_latency.py 2>/dev/null | grep "per call" 
 timeout -k 10 100 ./tools/keccak_wave_ubench.bin > "$OUT/keccak_wave_ubench.txt" 2>&1 || { echo "FAILED keccak_wave_ubench" >&2; exit 1; }
 timeout -k 10 100 ./tools/small_stamps.bin > "$OUT/small_stamps.txt" 2>&1 || { echo "FAILED small_stamps" >&2; exit 1; }
 timeout -k 10 100 ./tools/host_path_breakdown.bin > "$OUT/host_path_breakdown.txt" 2>&1 || { echo "FAILED host_path_breakdown" >&2; exit 1; }
-{ echo "# C++ host threads (tools/host_threads_c.cpp)"; timeout -k 10 200 ./tools/host_threads_c.bin && MLKEM_HOST_LANES=0 timeout -k 10 200 ./tools/host_threads_c.bin && echo "# Python host threads (tools/host_threads.py)" && timeout -k 10 200 python3 tools/host_threads.py 2>/dev/null | grep threads= && MLKEM_HOST_LANES=0 timeout -k 10 200 python3 tools/host_threads.py 2>/dev/null | grep threads=; } > "$OUT/host_threads.txt" || { echo "FAILED host_threads" >&2; exit 1; }
+{ echo "# C++ host threads (tools/host_threads_c.cpp): default (lanes + combining), lanes only, one engine"; timeout -k 10 200 ./tools/host_threads_c.bin && MLKEM_HOST_COMBINE=0 timeout -k 10 200 ./tools/host_threads_c.bin && MLKEM_HOST_COMBINE=0 MLKEM_HOST_LANES=0 timeout -k 10 200 ./tools/host_threads_c.bin && echo "# Python host threads (tools/host_threads.py): default" && timeout -k 10 200 python3 tools/host_threads.py 2>/dev/null | grep threads=; } > "$OUT/host_threads.txt" || { echo "FAILED host_threads" >&2; exit 1; }
 timeout -k 10 200 python3 tools/soak_small.py 60 2>/dev/null | grep "small-call soak" > "$OUT/soak_small.txt" || { echo "FAILED soak_small" >&2; exit 1; }
 timeout -k 10 300 python3 tools/energy_probe.py 2>/dev/null > "$OUT/energy.txt" || { echo "FAILED energy_probe" >&2; exit 1; }
 timeout -k 10 600 python3 -m pytest tests -m gpu -q 2>&1 | tail -3 > "$OUT/gpu_tier.log" || { echo "FAILED gpu tier" >&2; cat "$OUT/gpu_tier.log" >&2; exit 1; }
