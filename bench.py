@@ -19,7 +19,7 @@ the aggregate; `correct` is the AND over all ranks and every rank exits non-zero
 --inproc: the same workload in ONE process through mlkem_{encaps,decaps}_multi_dev, one member per visible device (members
 repeat devices when there are fewer devices than --gpus: a rehearsal, labelled as such) -- the in-process form of the shard.
 
-At N = 1 the line also carries `also`: BASELINE configs[1] (NTT-only) and configs[3] (ML-KEM-1024 KeyGen+Encaps+Decaps)
+At N = 1 the line also carries `also`: BASELINE configs[1] (NTT-only), configs[3] (ML-KEM-1024 KeyGen+Encaps+Decaps), small_calls (1 / 64 / 768-item call pairs)
 measured in the same process right after the headline, each with value / ms_per_step / correct / roofline.
 
 Extra objects on the line:
@@ -733,6 +733,66 @@ def entry(workload, args, elapsed, ok, extra, world):
     return {"value": value, "ms_per_step": ms_step, "correct": ok, "roofline": roofline, "kernels": kernels, "energy": energy}
 
 
+def small_calls(device):
+    """The regime every call of the ml_kem.h drop-in API lives in, measured in the driver-observed run: ML-KEM-768 Encaps + Decaps
+    CALL PAIRS of 1 / 64 / 768 items -- device-resident buffers, calls queued back to back (launch overhead included), and the
+    host-pointer path of one item (what the shim calls: mlkem_encaps / mlkem_decaps on host memory, synchronous).  Every pair is
+    checked (K == K', status 0); a tampered ciphertext must be rejected."""
+    import ctypes as C
+    pkg = ge.load_package()
+    lib = pkg.load_library()
+    eng = pkg.MLKEM(768, device=device.index or 0, chunk_items=4096)
+    out = {"unit": "ms per Encaps + Decaps call pair (ML-KEM-768)", "device_resident": {}, "correct": True}
+    for n in (1, 64, 768):
+        d, z, m = (device_seeds(lbl, 0, n, device) for lbl in ("mlkem-bench-d", "mlkem-bench-z", "mlkem-bench-m"))
+        ek, dk = eng.keygen(d, z)
+        c = torch.empty((n, eng.c_len), dtype=torch.uint8, device=device)
+        K, K2 = (torch.empty((n, 32), dtype=torch.uint8, device=device) for _ in range(2))
+        st = torch.empty(n, dtype=torch.int32, device=device)
+        reps = 300
+
+        def pair():
+            eng.encaps(ek, m, c=c, K=K)
+            eng.decaps(dk, c, K=K2, status=st)
+        for _ in range(10):
+            pair()
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            pair()
+        torch.cuda.synchronize(device)
+        out["device_resident"][str(n)] = 1e3 * (time.perf_counter() - t0) / reps
+        good = bool(torch.equal(K, K2)) and int(st.abs().sum()) == 0
+        cb = c.clone()
+        cb[n - 1, 5] ^= 2
+        Kb, _ = eng.decaps(dk, cb)
+        good = good and not bool(torch.equal(Kb[n - 1], K[n - 1])) and bool(torch.equal(Kb[: n - 1], K[: n - 1]))
+        out["correct"] = out["correct"] and good
+    # host pointers, one item
+    ek_h, dk_h, m_h = (t.cpu().numpy().copy() for t in (ek[:1], dk[:1], m[:1]))
+    c_h, K_h, K2_h = np.zeros((1, eng.c_len), np.uint8), np.zeros((1, 32), np.uint8), np.zeros((1, 32), np.uint8)
+    st_h = np.ones(1, np.int32)
+    for f in (lib.mlkem_encaps, lib.mlkem_decaps):
+        f.argtypes = [C.c_int, C.c_size_t] + [C.c_void_p] * 4
+
+    def hpair():
+        rc = lib.mlkem_encaps(768, 1, ek_h.ctypes.data, m_h.ctypes.data, c_h.ctypes.data, K_h.ctypes.data)
+        return rc | lib.mlkem_decaps(768, 1, dk_h.ctypes.data, c_h.ctypes.data, K2_h.ctypes.data, st_h.ctypes.data)
+    rc = 0
+    for _ in range(10):
+        rc |= hpair()
+    t0 = time.perf_counter()
+    for _ in range(300):
+        rc |= hpair()
+    out["host_pointer"] = {"1": 1e3 * (time.perf_counter() - t0) / 300}
+    out["correct"] = out["correct"] and rc == 0 and bool((K_h == K2_h).all()) and int(st_h[0]) == 0 and bool((K_h == K[:1].cpu().numpy()).all())
+    out["note"] = ("one launch per operation, one workgroup per item (mlkem_small.hpp); host_pointer = mlkem_encaps + mlkem_decaps on host memory "
+                   "through ctypes, no copy commands (the kernels read and write pinned host memory)")
+    eng.close()
+    lib.mlkem_host_release()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -784,6 +844,8 @@ def main():
             also[wl2] = e2
             ok = ok and ok2
             torch.cuda.empty_cache()
+        also["small_calls"] = small_calls(device)
+        ok = ok and also["small_calls"]["correct"]
 
     # the gate of the whole job: every rank's bytes must be right; per-rank results travel to rank 0 over the control plane
     ok = all_ranks_ok(ok, device)

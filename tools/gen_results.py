@@ -165,6 +165,10 @@ def main():
         if e.get("cpu_baseline"):
             L.append("* CPU baseline:\n" + cpu_lines(e["cpu_baseline"]))
         L.append("")
+    sc = d.get("also", {}).get("small_calls")
+    if sc:
+        L.append("**Small calls** (same process, `also.small_calls`; %s): device-resident %s; host pointers, one item: %.3f; `correct: %s`\n" % (
+            sc["unit"], ", ".join("%s items: %.4f" % (k, v) for k, v in sc["device_resident"].items()), sc["host_pointer"]["1"], sc["correct"]))
     for name, title in (("bench_kem512.json", "ML-KEM-512 keygen+encaps+decaps"), ("bench_shared.json", "ML-KEM-768, one key pair for the whole batch (extra workload)")):
         j = load(name)
         if j:
