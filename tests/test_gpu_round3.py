@@ -301,6 +301,14 @@ sys.exit(1 if bad else 0)
     assert r.returncode == 0, r.stdout + r.stderr
 
 
+def test_small_call_kernels_soak_ten_seconds():
+    """tools/soak_small.py for ten seconds: keygen -> encaps -> decaps calls of random sizes 1..896 and random parameter sets on two
+    streams, every round checked, under a watchdog that ends the process if a round does not finish within 5 s (the small-call
+    kernels hand values over by spin-waiting on counters in LDS: a logic error there shows as a wave that never finishes)."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "soak_small.py"), "10"], capture_output=True, text=True, timeout=200, cwd=ROOT)
+    assert r.returncode == 0 and "mismatches 0" in r.stdout, r.stdout + r.stderr[-2000:]
+
+
 # ---- bench.py: the N > 1 line carries what configs[4] is defined by --------------------------------------------------------
 def _free_port():
     s = socket.socket()
