@@ -175,7 +175,7 @@ int mlkem_ctx_create(mlkem_ctx** out, int device, size_t chunk_items) {
     }
     if (const char* e = getenv("MLKEM_SMALL_ITEMS")) {       // 0: never the one-workgroup-per-item kernels
         long long v = atoll(e);
-        if (v >= 0) c->ws.small_max = (size_t)v;
+        if (v >= 0) c->ws.small_max_k[0] = c->ws.small_max_k[1] = c->ws.small_max_k[2] = (size_t)v;
     }
     if (const char* e = getenv("MLKEM_SMALL_WIDE_ITEMS")) {      // Decaps calls up to this size: twelve waves per item (k >= 3)
         long long v = atoll(e);
@@ -763,7 +763,7 @@ int stream_op(StreamEngine& e, size_t n, size_t chunk, const std::vector<Span>& 
     // MLKEM_ZERO_COPY=0 keeps the copy commands.  Measured up to 512 items; larger small calls keep the copy commands.
     constexpr size_t ZERO_COPY_MAX = 512;
     static const bool zero_copy = [] { const char* z = getenv("MLKEM_ZERO_COPY"); return !(z && atoi(z) == 0); }();
-    if (rc == MLKEM_OK && single && zero_copy && e.ctx && n <= e.ctx->ws.small_max && n <= ZERO_COPY_MAX) {
+    if (rc == MLKEM_OK && single && zero_copy && e.ctx && n <= e.ctx->ws.small_max(4) && n <= ZERO_COPY_MAX) {   // (k = 4 has the lowest limit, above ZERO_COPY_MAX by default)
         BufSet& s = e.set[0];
         bool ok = true;
         for (size_t j = 0; j < spans.size() && ok; j++) {

@@ -114,9 +114,13 @@ struct Workspace {
     size_t hcap = 0;   // h-chunk capacity (items) of the 32-byte arrays
     size_t wide_max = 2048;   // calls of at most this many items hash with one sponge per HALF-WAVE (mlkem_wkeccak.hpp: faster
                               // up to 2048 items, slower from 4096, profiles/r03_batch_sweep.txt); env MLKEM_WIDE_HASH_ITEMS
-    size_t small_max = 896;   // calls of at most this many items run as ONE launch, one workgroup per item (mlkem_small.hpp); per pair
-                              // at 768 items 0.160 ms against 0.198 on the batch path, at 1024 0.211 against 0.194
-                              // (profiles/r04_small_sweep.txt); env MLKEM_SMALL_ITEMS (0: never)
+    // calls of at most small_max_k[k - 2] items run as ONE launch, one workgroup per item (mlkem_small.hpp).  Per parameter set: the
+    // limit is what the chip takes in ONE round of four-wave workgroups -- 6 / 3 / 2 per CU at k = 2 / 3 / 4 (91-122 / 118-178 /
+    // 152-226 VGPRs) x 256 CUs; a second round loses to the batch path (small against batch, ms per call triple or pair:
+    // ML-KEM-512 0.281 / 0.305 at 1536 items, 0.318 / 0.315 at 1792; ML-KEM-768 0.156 / 0.193 at 768, 0.199 / 0.193 at 896;
+    // ML-KEM-1024 0.278 / 0.313 at 512, 0.387 / 0.326 at 576; profiles/r04_small_limits.txt).  env MLKEM_SMALL_ITEMS sets all three (0: never)
+    size_t small_max_k[3] = {1536, 768, 512};
+    size_t small_max(int k) const { return small_max_k[k - 2]; }
     size_t small_lat_max = 320;   // ... of which calls of at most this many items use eight waves per item (shortest chain: 0.070
                                   // against 0.083 ms per pair at one item, 0.077 against 0.095 at 256), larger ones four (twice the
                                   // items per CU: 0.115 against 0.117 at 384, 0.160 against 0.183 at 768); env MLKEM_SMALL_LATENCY_ITEMS
@@ -238,7 +242,7 @@ inline void keygen_run(stream_t st, const ParamSet& p, size_t n, const uint8_t* 
                        const Workspace& ws) {
     const bool kem = z != nullptr;
     const size_t dk_len = kem ? (size_t)p.dk_len : (size_t)(384 * K);
-    if (n && n <= ws.small_max) {   // small call: one launch, one workgroup per item (its intermediates live in LDS: no scratch)
+    if (n && n <= ws.small_max(K)) {   // small call: one launch, one workgroup per item (its intermediates live in LDS: no scratch)
         const int rate = ws.fips ? 136 : 168;
 #define MLKEM_KS(KEM, NW) launch("k_keygen_small", k_keygen_small<K, ETA1, KEM, NW>, n, WAVE * NW, st, n, d, z, ek, dk, rate)
         const bool lat = n <= ws.small_lat_max;
@@ -277,7 +281,7 @@ template <int K, int ETA1, int DU, int DV>
 inline void encaps_run(stream_t st, const ParamSet& p, size_t n, const uint8_t* ek, const uint8_t* m, uint8_t* c, uint8_t* Kout,
                        int32_t* mod_status, const Workspace& ws, const uint8_t* r_user = nullptr) {
     if (n == 0) return;
-    if (!r_user && n <= ws.small_max) {   // small call: one launch, one workgroup per item
+    if (!r_user && n <= ws.small_max(K)) {   // small call: one launch, one workgroup per item
         const int rate = ws.fips ? 136 : 168;
         if (n <= ws.small_lat_max)
             launch("k_encaps_small", k_encaps_small<K, ETA1, DU, DV, SMALL_WAVES>, n, WAVE * SMALL_WAVES, st, n, ek, m, c, Kout, mod_status, rate);
@@ -325,7 +329,7 @@ template <int K, int ETA1, int DU, int DV>
 inline void decaps_run(stream_t st, const ParamSet& p, size_t n, const uint8_t* dk, const uint8_t* c, uint8_t* Kout,
                        int32_t* status, bool hash_check, const Workspace& ws) {
     constexpr int CLEN = 32 * (DU * K + DV);
-    if (n && n <= ws.small_max) {   // small call: one launch, one workgroup per item
+    if (n && n <= ws.small_max(K)) {   // small call: one launch, one workgroup per item
         const int rate = ws.fips ? 136 : 168;
         int32_t* sts = hash_check ? status : (int32_t*)nullptr;
 #define MLKEM_DS(HC, JR, NW) launch("k_decaps_small", k_decaps_small<K, ETA1, DU, DV, HC, JR, NW>, (HC) ? 2 * n : n, WAVE * NW, st, n, dk, c, Kout, sts, rate)

@@ -66,7 +66,9 @@ typedef struct mlkem_ctx mlkem_ctx;
  * The context gets one side stream with its first encaps / decaps call of at most `chunk_items` items (env
  * MLKEM_SIDE_STREAM=0: never): such a call samples its matrix there while the hash kernels run on the caller's stream; fork and
  * join are events inside the call, so the caller's stream is ordered after all of the call's work exactly as without it
- * (stream capture sees a fork/join).  Contexts that only ever see larger calls create no stream. */
+ * (stream capture sees a fork/join).  Contexts that only ever see larger calls create no stream.
+ * A context's scratch serves ONE call at a time: queue the *_dev calls of a context on one stream (or order the streams
+ * yourself); work that runs side by side on several streams needs a context per stream. */
 MLKEM_API int mlkem_ctx_create(mlkem_ctx** out, int device, size_t chunk_items);
 MLKEM_API void mlkem_ctx_destroy(mlkem_ctx* ctx);
 MLKEM_API size_t mlkem_ctx_scratch_bytes(const mlkem_ctx* ctx);

@@ -26,7 +26,7 @@ static Workspace make_ws(size_t n) {
     if (ws.hcap < ws.cap) ws.hcap = ws.cap;
     ws.fips = g_fips;
     ws.wide_max = g_wide;
-    ws.small_max = g_small;
+    ws.small_max_k[0] = ws.small_max_k[1] = ws.small_max_k[2] = g_small;
     ws.small_lat_max = g_small_lat;
     ws.small_wide_max = g_small_wide;
     ws.A = (uint16_t*)xalloc(ws.cap * 16 * 512);

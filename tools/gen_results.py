@@ -226,6 +226,7 @@ def main():
                         ("keygen_latency.txt", "Device-resident call latency per parameter set and operation (`tools/keygen_latency.py`)"),
                         ("host_path_breakdown.txt", "Host-pointer call of one item from C: launch floor, device buffers, host buffers (`tools/host_path_breakdown.hip`)"),
                         ("host_threads.txt", "One-item host-pointer pairs from T host threads at once, with and without engine lanes (`tools/host_threads_c.cpp`, `tools/host_threads.py`)"),
+                        ("small_limits.txt", "Small-call limit per parameter set: one workgroup per item against the batch path"),
                         ("small_sweep.txt", "Small calls: one workgroup per item (eight / four waves) against the batch path (`tools/small_sweep.sh`)"),
                         ("energy.txt", "Energy by kernel family, each looped alone at its 2^20 shapes (`tools/energy_probe.py`)"),
                         ("keccak_wave_ubench.txt", "Keccak-f[1600] of a lone wave: lane-sliced / half-wave (round 3) / wave-wide (`tools/keccak_wave_ubench.hip`)")):

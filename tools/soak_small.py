@@ -18,7 +18,8 @@ import __graft_entry__ as ge  # noqa: E402
 seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 pkg = ge.load_package()
 dev = torch.device("cuda", 0)
-engines = {s: pkg.MLKEM(s, device=0, chunk_items=4096) for s in (512, 768, 1024)}
+# one context per parameter set AND stream: a context's scratch serves one call at a time (sizes above a set's small-call limit take the batch path)
+engines = {(s, i): pkg.MLKEM(s, device=0, chunk_items=4096) for s in (512, 768, 1024) for i in range(2)}
 rng = np.random.default_rng(2024)
 sizes = [1, 2, 3, 7, 64, 127, 128, 129, 255, 256, 257, 319, 320, 321, 500, 768, 895, 896]
 streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
@@ -42,11 +43,11 @@ rounds = calls = items = 0
 bad = 0
 while time.perf_counter() - t0 < seconds:
     pend = []
-    for s in streams:
+    for si, s in enumerate(streams):
         with torch.cuda.stream(s):
             pset = int(rng.choice((512, 768, 1024)))
             n = int(rng.choice(sizes)) if rng.random() < 0.7 else int(rng.integers(1, 897))
-            e = engines[pset]
+            e = engines[(pset, si)]
             d, z, m = (torch.from_numpy(rng.integers(0, 256, (n, 32), dtype=np.uint8)).to(dev, non_blocking=True) for _ in range(3))
             ek, dk = e.keygen(d, z)
             c, K = e.encaps(ek, m)
