@@ -121,9 +121,10 @@ struct Workspace {
     // ML-KEM-1024 0.278 / 0.313 at 512, 0.387 / 0.326 at 576; profiles/r04_small_limits.txt).  env MLKEM_SMALL_ITEMS sets all three (0: never)
     size_t small_max_k[3] = {1536, 768, 512};
     size_t small_max(int k) const { return small_max_k[k - 2]; }
-    size_t small_lat_max = 320;   // ... of which calls of at most this many items use eight waves per item (shortest chain: 0.070
-                                  // against 0.083 ms per pair at one item, 0.077 against 0.095 at 256), larger ones four (twice the
-                                  // items per CU: 0.115 against 0.117 at 384, 0.160 against 0.183 at 768); env MLKEM_SMALL_LATENCY_ITEMS
+    size_t small_lat_max = 256;   // ... of which calls of at most this many items use eight waves per item (shortest chain: 0.070
+                                  // against 0.083 ms per ML-KEM-768 pair at one item, 0.085 against 0.090 at 256), larger ones four:
+                                  // beyond one workgroup per CU the eight-wave form needs a second round in every parameter set
+                                  // (768: 0.118 against 0.110 at 288; 1024: 0.323 against 0.268; 512: a tie); env MLKEM_SMALL_LATENCY_ITEMS
     size_t small_wide_max = 128;  // ... and Decaps calls of at most this many items twelve (k >= 3); env MLKEM_SMALL_WIDE_ITEMS
     // measurement aid (mlkem_ctx_debug_stages, tools/energy_probe.py): which kernel families the batch path launches; the
     // outputs of a call with stages missing are meaningless.  1 = hash kernels, 2 = sampler, 4 = K-PKE.Encrypt / KeyGen, 8 = Decrypt

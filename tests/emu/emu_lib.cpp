@@ -13,7 +13,7 @@ static size_t g_cap = 0, g_hcap = 0;
 static int g_fips = 0;
 static size_t g_wide = 0;       // items up to which the one-sponge-per-wave hash kernels run (64 host threads shuffle slowly: off unless a test asks)
 static size_t g_small = 0;      // items up to which the one-workgroup-per-item kernels run (512 host threads per item: off unless a test asks)
-static size_t g_small_lat = 128; // ... of which calls up to this size use eight waves per item, larger ones four
+static size_t g_small_lat = 256; // ... of which calls up to this size use eight waves per item, larger ones four
 static size_t g_small_wide = 0;  // ... and Decaps calls up to this size twelve (768 host threads per item: off unless a test asks)
 static int g_resume_cap = 64;   // resume records per chunk; a small value exercises the overflow into the restart list
 

@@ -578,7 +578,7 @@ def test_emu_one_workgroup_per_item_kernels(emu, oracle, pset, fips, waves):
         assert st[0] == -5 and (Kd[0] == oracle.decaps_internal(pset, dkb[0], c[0])).all()   # G ran on the corrupted stored h
     finally:
         emu.emu_small(C.c_size_t(0))
-        emu.emu_small_latency(C.c_size_t(128))
+        emu.emu_small_latency(C.c_size_t(256))
         emu.emu_small_wide(C.c_size_t(0))
         emu.emu_conformance(0)
         oracle.set_conformance(False)

@@ -443,10 +443,11 @@ def test_single_chunk_calls_keep_their_results_with_and_without_the_side_stream(
 @pytest.mark.parametrize("pset,n", tuple((768, n) for n in (1, 2, 128, 129, 256, 257, 320, 321, 512, 767, 768, 769, 2047, 2048, 2049))
                          + ((512, 1536), (512, 1537), (1024, 512), (1024, 513)))
 def test_default_path_switches_at_their_boundaries(pkg, torch, oracle, pset, n):
-    """The sizes either side of Workspace::small_wide_max (128: Decaps with twelve | eight waves per item), Workspace::small_lat_max (320: one workgroup of eight | of four waves per item; 256 | 257: the end
-    of the eight-wave form's first round), Workspace::small_max(3) (768: one workgroup per item | batch kernels) and Workspace::wide_max
-    (2048: one sponge per wave + direct sampler | lane-sliced hashes + three-block sampler), default environment, one chunk
-    (chunk_items 4096; for ML-KEM-512 / 1024 the sizes either side of their own small_max, 1536 / 512): keygen -> encaps -> decaps with tampered ciphertexts and one corrupted stored hash."""
+    """The sizes either side of every switch of the default path, one chunk (chunk_items 4096), default environment: Workspace::
+    small_wide_max (128 | 129: Decaps with twelve | eight waves per item), small_lat_max (256 | 257: one workgroup of eight | of four
+    waves per item; 320, 321, 512: inside the four-wave range), small_max (ML-KEM-768: 768 | 769, ML-KEM-512: 1536 | 1537,
+    ML-KEM-1024: 512 | 513: one workgroup per item | batch kernels) and wide_max (2048 | 2049: one sponge per wave + direct sampler |
+    lane-sliced hashes + three-block sampler): keygen -> encaps -> decaps with tampered ciphertexts and one corrupted stored hash."""
     k = {512: 2, 768: 3, 1024: 4}[pset]
     e = pkg.MLKEM(pset, device=0, chunk_items=4096)
     d, z, m = seeds("bd-d", n, pset), seeds("bd-z", n, pset), seeds("bd-m", n, pset)
