@@ -537,7 +537,7 @@ def test_emu_one_sponge_per_wave_hash_kernels(emu, oracle, pset, fips):
         oracle.set_conformance(False)
 
 
-@pytest.mark.parametrize("pset,fips,waves", ((512, 0, 4), (768, 0, 8), (1024, 1, 12)))
+@pytest.mark.parametrize("pset,fips,waves", ((512, 0, 4), (768, 0, 8), (768, 0, 4), (1024, 1, 12)))
 def test_emu_one_workgroup_per_item_kernels(emu, oracle, pset, fips, waves):
     """mlkem_small.hpp (calls of at most `small_max` items): KeyGen, Encaps and Decaps each as ONE launch, a workgroup of eight
     (latency form; twelve for Decaps of 1024) or four (dense form) waves per item -- wave-level SampleNTT (ballot + prefix-count
