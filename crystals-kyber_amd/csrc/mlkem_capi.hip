@@ -171,7 +171,7 @@ int mlkem_ctx_create(mlkem_ctx** out, int device, size_t chunk_items) {
     c->ws.hcap = hn;
     if (const char* e = getenv("MLKEM_WIDE_HASH_ITEMS")) {   // 0: always the lane-sliced hash kernels
         long long v = atoll(e);
-        if (v >= 0) c->ws.wide_max = (size_t)v;
+        if (v >= 0) c->ws.wide_max = c->ws.wide_max_k[0] = c->ws.wide_max_k[1] = c->ws.wide_max_k[2] = (size_t)v;
     }
     if (const char* e = getenv("MLKEM_SMALL_ITEMS")) {       // 0: never the one-workgroup-per-item kernels
         long long v = atoll(e);

@@ -112,8 +112,14 @@ struct Workspace {
     uint32_t resume_cap = 0;    // records `resume` has room for
     size_t cap = 0;    // chunk capacity (items) of A / prf / leftover
     size_t hcap = 0;   // h-chunk capacity (items) of the 32-byte arrays
-    size_t wide_max = 2048;   // calls of at most this many items hash with one sponge per HALF-WAVE (mlkem_wkeccak.hpp: faster
-                              // up to 2048 items, slower from 4096, profiles/r03_batch_sweep.txt); env MLKEM_WIDE_HASH_ITEMS
+    size_t wide_max = 2048;   // stand-alone SampleNTT / sponge calls of at most this many inputs run one sponge per wavefront
+    // KEM calls of at most wide_max_k[k - 2] items (and more than small_max) hash with one sponge per WAVEFRONT (mlkem_wkeccak.hpp) and
+    // sample in direct mode (one launch).  ms per ML-KEM-768 pair, this form against lane-sliced: 0.257 / 0.297 at 2304 items,
+    // 0.273 / 0.301 at 2816, 0.302 / 0.295 at 3328; ML-KEM-1024 triple 0.454 / 0.594 at 2304, 0.579 / 0.611 at 3840, 0.699 / 0.663 at
+    // 4608; ML-KEM-512 0.397 / 0.410 at 3840, 0.433 / 0.422 at 4608 (profiles/r04_small_limits.txt).  env MLKEM_WIDE_HASH_ITEMS sets
+    // all of them (0: always the lane-sliced hash kernels)
+    size_t wide_max_k[3] = {4096, 3072, 4096};
+    size_t wide_kem(int k) const { return wide_max_k[k - 2]; }
     // calls of at most small_max_k[k - 2] items run as ONE launch, one workgroup per item (mlkem_small.hpp).  Per parameter set: the
     // limit is what the chip takes in ONE round of four-wave workgroups -- 6 / 3 / 2 per CU at k = 2 / 3 / 4 (91-122 / 118-178 /
     // 152-226 VGPRs) x 256 CUs; a second round loses to the batch path (small against batch, ms per call triple or pair:
@@ -203,7 +209,7 @@ inline void launch_sample_split(stream_t st, const ParamSet& p, size_t n_xof_ite
     a.prf_rate = ws.fips ? 136 : 168;
     const size_t grid = a.xof_blocks + ceil_div(a.n_prf, WAVE);
     if (grid == 0) return;
-    if (n_xof_items <= ws.wide_max && n_prf_items <= ws.wide_max) {
+    if (n_xof_items <= ws.wide_kem(p.k) && n_prf_items <= ws.wide_kem(p.k)) {
         // small call: the general sampler finishes every sponge itself (a wave runs a fourth permutation when one of its lanes
         // needs it) -- one launch instead of three, 0.045 instead of 0.08 ms on the call's critical path; at full batches the
         // three-block kernel + hand-over is 13 % cheaper (mlkem_sampler.hpp)
@@ -268,7 +274,7 @@ inline void keygen_run(stream_t st, const ParamSet& p, size_t n, const uint8_t* 
                 launch("k_keygen", k_keygen2<K, ETA1, false>, kgrid, WAVE * KPKE2_WAVES, st, cn, (const uint16_t*)ws.A, (const uint8_t*)ws.prf,
                        (const uint8_t*)(ws.rho + c0 * 32), ek + i0 * p.ek_len, dk + i0 * dk_len);
         }
-        if (kem && n <= ws.wide_max)   // small call: one sponge per wave (mlkem_wkeccak.hpp)
+        if (kem && n <= ws.wide_kem(K))   // small call: one sponge per wave (mlkem_wkeccak.hpp)
             launch("k_hash_keygen_fin", k_hash_keygen_fin_w<K>, hn, WAVE, st, hn, (const uint8_t*)(ek + h0 * p.ek_len), z + h0 * 32, dk + h0 * p.dk_len);
         else if (kem)
             launch("k_hash_keygen_fin", k_hash_keygen_fin<K>, ceil_div(hn, WAVE), WAVE, st, hn, (const uint8_t*)(ek + h0 * p.ek_len),
@@ -296,7 +302,7 @@ inline void encaps_run(stream_t st, const ParamSet& p, size_t n, const uint8_t* 
         const size_t hn = min_sz(ws.hcap, n - h0);
         const uint8_t* r_h = r_user ? r_user + h0 * 32 : (const uint8_t*)ws.r;
         if (!(ws.stages & 1u)) {
-        } else if (!r_user && n <= ws.wide_max)   // mid-size call: one sponge per wave (mlkem_wkeccak.hpp)
+        } else if (!r_user && n <= ws.wide_kem(K))   // mid-size call: one sponge per wave (mlkem_wkeccak.hpp)
             launch("k_hash_encaps", k_hash_encaps_w<K>, hn, WAVE, st, hn, ek + h0 * p.ek_len, m + h0 * 32, Kout + h0 * 32, ws.r);
         else if (!r_user)
             launch("k_hash_encaps", k_hash_encaps<K>, ceil_div(hn, WAVE), WAVE, st, hn, ek + h0 * p.ek_len, m + h0 * 32, Kout + h0 * 32, ws.r);
@@ -354,7 +360,7 @@ inline void decaps_run(stream_t st, const ParamSet& p, size_t n, const uint8_t* 
         int32_t* sth = (hash_check && status) ? status + h0 : (int32_t*)nullptr;
         const size_t hgrid = ceil_div(hn, WAVE);
         if (!(ws.stages & 1u)) {
-        } else if (n <= ws.wide_max) {   // small call: one sponge per wave (mlkem_wkeccak.hpp)
+        } else if (n <= ws.wide_kem(K)) {   // small call: one sponge per wave (mlkem_wkeccak.hpp)
             if (hash_check && !ws.fips)
                 launch("k_hash_decaps", k_hash_decaps_w<K, CLEN, true, 168>, 2 * hn, WAVE, st, hn, dkh, ch, (const uint8_t*)ws.m, ws.Kp, ws.r, ws.Kbar, sth, (size_t)p.dk_len);
             else if (!ws.fips)

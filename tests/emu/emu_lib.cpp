@@ -25,7 +25,7 @@ static Workspace make_ws(size_t n) {
     ws.hcap = g_hcap ? g_hcap : (n ? n : 1);
     if (ws.hcap < ws.cap) ws.hcap = ws.cap;
     ws.fips = g_fips;
-    ws.wide_max = g_wide;
+    ws.wide_max = ws.wide_max_k[0] = ws.wide_max_k[1] = ws.wide_max_k[2] = g_wide;
     ws.small_max_k[0] = ws.small_max_k[1] = ws.small_max_k[2] = g_small;
     ws.small_lat_max = g_small_lat;
     ws.small_wide_max = g_small_wide;
@@ -61,7 +61,7 @@ static long compress_f_mismatches() {
 template <int QB, int CAP>
 static int sample_matrix_bounded(int k, size_t n, const uint8_t* rho, int transpose, uint16_t* A_out, int direct) {
     Workspace ws = make_ws(n);
-    ws.wide_max = direct ? n : 0;
+    ws.wide_max = ws.wide_max_k[0] = ws.wide_max_k[1] = ws.wide_max_k[2] = direct ? n : 0;
     ParamSet p;
     param_set(k == 2 ? 512 : k == 3 ? 768 : 1024, p);
     uint8_t* r = (uint8_t*)xalloc(n * 32);

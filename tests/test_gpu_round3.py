@@ -440,16 +440,17 @@ def test_single_chunk_calls_keep_their_results_with_and_without_the_side_stream(
     e.close()
 
 
-@pytest.mark.parametrize("pset,n", tuple((768, n) for n in (1, 2, 128, 129, 256, 257, 320, 321, 512, 767, 768, 769, 2047, 2048, 2049))
-                         + ((512, 1536), (512, 1537), (1024, 512), (1024, 513)))
+@pytest.mark.parametrize("pset,n", tuple((768, n) for n in (1, 2, 128, 129, 256, 257, 320, 321, 512, 767, 768, 769, 2048, 2049, 3071, 3072, 3073))
+                         + ((512, 1536), (512, 1537), (512, 4096), (512, 4097), (1024, 512), (1024, 513), (1024, 4096), (1024, 4097)))
 def test_default_path_switches_at_their_boundaries(pkg, torch, oracle, pset, n):
-    """The sizes either side of every switch of the default path, one chunk (chunk_items 4096), default environment: Workspace::
+    """The sizes either side of every switch of the default path, one chunk (chunk_items 8192), default environment: Workspace::
     small_wide_max (128 | 129: Decaps with twelve | eight waves per item), small_lat_max (256 | 257: one workgroup of eight | of four
     waves per item; 320, 321, 512: inside the four-wave range), small_max (ML-KEM-768: 768 | 769, ML-KEM-512: 1536 | 1537,
-    ML-KEM-1024: 512 | 513: one workgroup per item | batch kernels) and wide_max (2048 | 2049: one sponge per wave + direct sampler |
-    lane-sliced hashes + three-block sampler): keygen -> encaps -> decaps with tampered ciphertexts and one corrupted stored hash."""
+    ML-KEM-1024: 512 | 513: one workgroup per item | batch kernels) and wide_max_k (ML-KEM-768: 3072 | 3073, ML-KEM-512 and 1024:
+    4096 | 4097: one sponge per wave + direct sampler | lane-sliced hashes + three-block sampler; 2048 | 2049: the limit of the
+    stand-alone primitives, inside the range): keygen -> encaps -> decaps with tampered ciphertexts and one corrupted stored hash."""
     k = {512: 2, 768: 3, 1024: 4}[pset]
-    e = pkg.MLKEM(pset, device=0, chunk_items=4096)
+    e = pkg.MLKEM(pset, device=0, chunk_items=8192)
     d, z, m = seeds("bd-d", n, pset), seeds("bd-z", n, pset), seeds("bd-m", n, pset)
     ek, dk = e.keygen(dev(torch, d), dev(torch, z))
     c, K = e.encaps(ek, dev(torch, m))
